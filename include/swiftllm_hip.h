@@ -1,0 +1,203 @@
+/*
+ * swiftllm_hip.h — C ABI of libswiftllm_hip.so
+ *
+ * The drop-in boundary for swiftLLM's data plane (LlamaModel.forward) on MI355X / gfx950.
+ * Every entry point replaces one operator of the reference's Python/Triton operator layer
+ * (the modules under swiftllm/worker/kernels) or its one native function (csrc/src/block_swapping.cpp).
+ * The reference file:line each entry replaces is cited above its declaration.
+ *
+ * Conventions
+ *   - plain `extern "C"`, device pointers as void*, sizes as int32/int64, no torch types;
+ *   - `dtype`: SWL_F16 (the reference's hard-coded precision) or SWL_BF16 (headline precision);
+ *   - `stream` is a hipStream_t passed as void*; NOTHING is ever launched on the null stream
+ *     unless the caller passes NULL explicitly. No allocation, no synchronisation, no global
+ *     state: every call is re-entrant and may be captured into a hipGraph;
+ *   - returns SWL_OK (0) or a negative SWL_ERR_* code; the Python shim maps non-zero to
+ *     RuntimeError (the reference surfaces failures as AssertionError/RuntimeError);
+ *   - zero-size batches are legal everywhere and return SWL_OK without launching
+ *     (the reference's idle engine spins on empty forwards: server/engine.py:115-171);
+ *   - all offsets into the KV pools are 64-bit (288 GB pools exceed 2^31 elements).
+ *
+ * KV pool layout (reference model.py:138-148): [num_blocks, num_layers, num_kv_heads, block_size, head_dim],
+ * contiguous, one pool for K and one for V.
+ */
+#ifndef SWIFTLLM_HIP_H
+#define SWIFTLLM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWL_ABI_VERSION 1
+
+#define SWL_F16 0
+#define SWL_BF16 1
+
+#define SWL_OK 0
+#define SWL_ERR_BAD_ARG (-1)     /* null pointer, negative size, misaligned pointer/stride          */
+#define SWL_ERR_UNSUPPORTED (-2) /* shape outside what the kernels are specialised for              */
+#define SWL_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after the launch                */
+#define SWL_ERR_RUNTIME (-4)     /* a HIP runtime call (memcpy) failed                              */
+
+typedef void *swl_stream_t; /* hipStream_t */
+
+int swl_abi_version(void);
+/* Human-readable name for an SWL_ERR_* code. */
+const char *swl_strerror(int code);
+
+/* ---- RMSNorm ------------------------------------------------------------------------------
+ * reference: rmsnorm.py:5-37 (_fwd_rmsnorm / rmsnorm_inplace)
+ * x[T, hidden] <- x * rsqrt(mean(x^2) + eps) * w      (fp32 math, one rounding to dtype)
+ * hidden % 8 == 0, hidden <= 16384; rows contiguous (row stride == hidden). */
+int swl_rmsnorm(void *x, const void *w, float eps, int64_t num_tokens, int32_t hidden,
+                int32_t dtype, swl_stream_t stream);
+
+/* reference: rmsnorm.py:39-89 (_fwd_fused_add_rmsnorm / fused_add_rmsnorm_inplace)
+ * residual <- x + residual (rounded to dtype and stored); x <- rmsnorm(residual) * w. */
+int swl_fused_add_rmsnorm(void *x, void *residual, const void *w, float eps, int64_t num_tokens,
+                          int32_t hidden, int32_t dtype, swl_stream_t stream);
+
+/* ---- Rotary embedding ---------------------------------------------------------------------
+ * reference: rotary_emb.py:7-58 (_fwd_rotary_embedding / rotary_embedding_inplace)
+ * rotate-half RoPE in place on q[T, H, D] and k[T, KVH, D]; every multiply/add is rounded to
+ * dtype as in the reference. cos/sin are [rows, D/2] in dtype. If pos_idx != NULL the row used
+ * for token t is pos_idx[t] (tables = the model's full rope cache, model.py:224-225); if NULL
+ * the row is t (tables already gathered: model.py:350-351).
+ * q_tok_stride / k_tok_stride: elements between consecutive tokens (>= H*D / KVH*D; lets q,k be
+ * column slices of one fused qkv GEMM output). D in {32, 64, 128, 256}. */
+int swl_rotary(void *q, void *k, const void *cos_table, const void *sin_table,
+               const int32_t *pos_idx, int64_t num_tokens, int32_t num_q_heads,
+               int32_t num_kv_heads, int32_t head_dim, int64_t q_tok_stride, int64_t k_tok_stride,
+               int32_t dtype, swl_stream_t stream);
+
+/* ---- KV-cache store -----------------------------------------------------------------------
+ * reference: kvcache_mgmt.py:10-48 (_fwd_kvcache_mgmt_prefill_kernel), launcher :81-109
+ * For prefill seq s (id seq_ids[s], tokens [start_locs[s], +seq_lens[s]) of k/v), logical block j:
+ * pool[block_table[seq_id, j], layer, kvh, t % bs, :] = k[start + j*bs + t, kvh, :]   (bit-exact). */
+int swl_store_kv_prefill(void *k_cache, void *v_cache, const void *k, const void *v,
+                         const int32_t *block_table, const int32_t *seq_ids,
+                         const int32_t *start_locs, const int32_t *seq_lens,
+                         int32_t num_prefill_seqs, int32_t max_prefill_len, int32_t cur_layer,
+                         int32_t num_layers, int32_t num_kv_heads, int32_t block_size,
+                         int32_t head_dim, int32_t max_blocks_per_seq, int64_t k_tok_stride,
+                         int64_t v_tok_stride, int32_t dtype, swl_stream_t stream);
+
+/* reference: kvcache_mgmt.py:50-79 (_fwd_kvcache_mgmt_decoding_kernel), launcher :111-122
+ * For decoding seq i (length len_i INCLUDING the new token): token i of k/v goes to slot
+ * (block_table[seq_id, (len-1)/bs], (len-1)%bs). */
+int swl_store_kv_decode(void *k_cache, void *v_cache, const void *k, const void *v,
+                        const int32_t *block_table, const int32_t *seq_ids,
+                        const int32_t *seq_lens, int32_t num_decoding_seqs, int32_t cur_layer,
+                        int32_t num_layers, int32_t num_kv_heads, int32_t block_size,
+                        int32_t head_dim, int32_t max_blocks_per_seq, int64_t k_tok_stride,
+                        int64_t v_tok_stride, int32_t dtype, swl_stream_t stream);
+
+/* ---- SiLU-gate ----------------------------------------------------------------------------
+ * reference: silu_and_mul.py:5-34 (_fwd_silu_and_mul / silu_and_mul_inplace)
+ * x[T, 2*I]: x[:, :I] <- x[:, :I] * round(silu_fp32(x[:, I:]))   (up = first half, gate = second,
+ * weight.py:133).  I % 8 == 0 (the reference needs I % 256 == 0). */
+int swl_silu_mul(void *x, int64_t num_tokens, int32_t ffn_inter_dim, int32_t dtype,
+                 swl_stream_t stream);
+
+/* ---- Paged attention, decode (flash-decoding, "paged attention v2") --------------------------
+ * reference: paged_attn.py:9-108 (phase 1), :111-149 (phase 2), launcher :152-222
+ * q[Bd, H, D] (token stride q_tok_stride), o[Bd, H, D] (token stride o_tok_stride).
+ * Phase 1 writes per (seq, q-head, seq-block) a normalised partial mid_o (fp32) and the base-2
+ * log-sum-exp mid_lse (fp32), phase 2 merges them; with num_seq_blocks == 1 phase 1 writes o
+ * directly. Scratch: mid_o [Bd, H, num_seq_blocks, D] fp32 followed by mid_lse [Bd, H, num_seq_blocks]
+ * fp32 — the same shapes the reference allocates at paged_attn.py:170-180.
+ * One workgroup serves ALL G = H/KVH q-heads of a kv-head, so every KV byte is fetched once.
+ * seq_block_size % block_size == 0; block_size == 16; D in {32, 64, 128}; G in {1, 2, 4, 8}. */
+size_t swl_paged_attn_scratch_bytes(int32_t num_decoding_seqs, int32_t num_q_heads,
+                                    int32_t head_dim, int32_t num_seq_blocks);
+
+int swl_paged_attn_decode(void *o, const void *q, const void *k_cache, const void *v_cache,
+                          const int32_t *block_table, const int32_t *seq_ids,
+                          const int32_t *seq_lens, void *scratch, float softmax_scale,
+                          int32_t num_decoding_seqs, int32_t num_q_heads, int32_t num_kv_heads,
+                          int32_t head_dim, int32_t num_layers, int32_t block_size,
+                          int32_t cur_layer, int32_t max_blocks_per_seq, int32_t seq_block_size,
+                          int32_t num_seq_blocks, int64_t q_tok_stride, int64_t o_tok_stride,
+                          int32_t dtype, swl_stream_t stream);
+
+/* Phase 1 / phase 2 separately (parity tests compare mid_o / mid_lse with the reference's). */
+int swl_paged_attn_phase1(void *o_direct, const void *q, const void *k_cache, const void *v_cache,
+                          const int32_t *block_table, const int32_t *seq_ids,
+                          const int32_t *seq_lens, float *mid_o, float *mid_lse,
+                          float softmax_scale, int32_t num_decoding_seqs, int32_t num_q_heads,
+                          int32_t num_kv_heads, int32_t head_dim, int32_t num_layers,
+                          int32_t block_size, int32_t cur_layer, int32_t max_blocks_per_seq,
+                          int32_t seq_block_size, int32_t num_seq_blocks, int64_t q_tok_stride,
+                          int64_t o_tok_stride, int32_t dtype, swl_stream_t stream);
+int swl_paged_attn_phase2(void *o, const float *mid_o, const float *mid_lse,
+                          const int32_t *seq_lens, int32_t num_decoding_seqs, int32_t num_q_heads,
+                          int32_t head_dim, int32_t seq_block_size, int32_t num_seq_blocks,
+                          int64_t o_tok_stride, int32_t dtype, swl_stream_t stream);
+
+/* ---- Prefill attention (varlen causal flash attention, GQA) -------------------------------------
+ * reference: the call at transformer_layer.py:83-96 (vllm_flash_attn.flash_attn_varlen_func) and its
+ * in-repo equivalent prefill_attn.py:9-139 (_fwd_prefill_attention / prefill_attention).
+ * q[P, H, D], k/v[P, KVH, D] are the FRESH projections (the paged pool is not read), cu_seqlens is
+ * prefill_seq_start_locs_with_end (int32 [Bp+1]); o[P, H, D]. MFMA 32x32x16, fp32 softmax.
+ * D in {64, 128}. */
+int swl_prefill_attn_varlen(void *o, const void *q, const void *k, const void *v,
+                            const int32_t *cu_seqlens, int32_t num_prefill_seqs,
+                            int32_t max_prefill_len, int32_t num_q_heads, int32_t num_kv_heads,
+                            int32_t head_dim, float softmax_scale, int64_t q_tok_stride,
+                            int64_t k_tok_stride, int64_t v_tok_stride, int64_t o_tok_stride,
+                            int32_t dtype, swl_stream_t stream);
+
+/* ---- Block-table maintenance ------------------------------------------------------------------
+ * reference: block_mgmt.py:5-46 (set), :49-80 (unset), :83-127 (gather + unset)
+ * block_table int32 [max_seqs, max_blocks_per_seq]; num_seq_allocated_blocks int32 [max_seqs];
+ * is_block_free uint8(bool) [num_blocks].
+ * set: for batch entry i (seq s): block_table[s, n_s : n_s + need_i] = candidates[off_i : off_i + need_i],
+ *      n_s += need_i, where off = exclusive cumsum(block_needed) (passed in by the caller). */
+int swl_block_table_set(int32_t *num_seq_allocated_blocks, int32_t *block_table,
+                        const int32_t *candidate_blocks, const int32_t *seq_ids,
+                        const int32_t *block_needed, const int32_t *block_needed_excl_cumsum,
+                        int32_t batch_size, int32_t max_blocks_per_seq, swl_stream_t stream);
+/* unset: is_block_free[block_table[s, 0:n_s]] = 1; n_s = 0. */
+int swl_block_table_unset(int32_t *num_seq_allocated_blocks, const int32_t *block_table,
+                          const int32_t *seq_ids, uint8_t *is_block_free, int32_t batch_size,
+                          int32_t max_blocks_per_seq, swl_stream_t stream);
+/* gather: out[off_i : off_i + n_s] = block_table[s, 0:n_s]; then unset. */
+int swl_block_table_gather(int32_t *num_seq_allocated_blocks, const int32_t *block_table,
+                           const int32_t *seq_ids, uint8_t *is_block_free,
+                           const int32_t *out_excl_cumsum, int32_t *gathered_block_ids,
+                           int32_t batch_size, int32_t max_blocks_per_seq, swl_stream_t stream);
+
+/* ---- Block swapping (host code) ---------------------------------------------------------------
+ * reference: csrc/src/block_swapping.cpp:22-85 (swap_blocks), binding csrc/src/entrypoints.cpp:5-7
+ * Copies block src_ids[i] -> dst_ids[i] for K and V between the GPU pools and the host swap pools,
+ * run-length-coalescing consecutive (src, dst) pairs into one hipMemcpyAsync each, on `stream`.
+ * src_ids/dst_ids are HOST arrays. block_bytes = bytes of one block in one pool. */
+int swl_swap_blocks(const int64_t *src_ids, const int64_t *dst_ids, int64_t num_blocks_to_swap,
+                    int32_t is_swap_in, void *k_cache, void *v_cache, void *k_swap, void *v_swap,
+                    int64_t block_bytes, swl_stream_t stream);
+
+/* ---- Fused hot-path helpers (no reference twin; result-identical compositions) ------------------
+ * Decode-only: rotary on q,k followed by the decode KV store of the rotated k and of v, in one launch
+ * (= swl_rotary(pos_idx) + swl_store_kv_decode). */
+int swl_rotary_store_kv_decode(void *q, void *k, const void *v, const void *cos_table,
+                               const void *sin_table, const int32_t *pos_idx, void *k_cache,
+                               void *v_cache, const int32_t *block_table, const int32_t *seq_ids,
+                               const int32_t *seq_lens, int32_t num_decoding_seqs,
+                               int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
+                               int32_t cur_layer, int32_t num_layers, int32_t block_size,
+                               int32_t max_blocks_per_seq, int64_t q_tok_stride,
+                               int64_t k_tok_stride, int64_t v_tok_stride, int32_t dtype,
+                               swl_stream_t stream);
+
+/* Per-step decode metadata derived on the device (so a captured hipGraph can be replayed):
+ * pos_idx[i] = seq_lens[i] - 1. */
+int swl_decode_positions(int32_t *pos_idx, const int32_t *seq_lens, int32_t num_decoding_seqs,
+                         swl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWIFTLLM_HIP_H */

@@ -1,0 +1,437 @@
+// paged_attn.hip — decode-stage paged attention ("paged attention v2" / flash-decoding) for gfx950.
+//
+// Replaces _fwd_paged_attention_phase1 (swiftllm/worker/kernels/paged_attn.py:9-108) and
+// _fwd_paged_attention_phase2 (paged_attn.py:111-149). The north-star kernel: HBM-bound,
+// algorithmic bytes per call = sum_i len_i * 2 * KVH * D * e  (every KV byte ONCE per kv-head)
+// + q/o (2*Bd*H*D*e) + partials.
+//
+// Design (MI355X-first, not the reference's one-warp-per-q-head mapping):
+//   * grid (seq-block, kv-head, sequence); a workgroup = 4 waves serves ALL G = H/KVH q-heads of its
+//     kv-head, so a KV tile is fetched once instead of G times (the reference leans on L2 for that);
+//   * the 16-token x D tile of one (block, layer, kv-head) is 4 KiB contiguous in the pool; a wave
+//     reads it with fully coalesced 16-byte-per-lane loads (lane -> token = i*TPI + lane/LPT,
+//     8-element chunk = lane%LPT), 1 KiB per instruction, non-temporal (read once);
+//   * waves stride over the 16-token blocks of the sequence block; the next block's K and V (8 KiB
+//     per wave) are in flight while the current one is consumed (register double buffering);
+//   * q.k partial dots with v_dot2c_f32_{f16,bf16} (fp32 accumulate), reduced across the LPT lanes
+//     of a token with DPP adds — no LDS, no ds_bpermute in the main loop;
+//   * every LPT-lane row keeps its own online-softmax state (max, sum, 8-wide slice of the
+//     accumulator for each of the G heads) so nothing crosses rows until the end; rows are merged
+//     once per workgroup with wave shuffles, waves once through 8 KiB of LDS;
+//   * block-table entries are scalar loads (the wave index is made provably uniform);
+//   * scores are kept UNscaled; scale*log2(e) is folded into the exp2 argument with one fma.
+// Numerics: fp32 scores/softmax/accumulation (the reference rounds scores to fp16,
+// paged_attn.py:72-73; ours is closer to the exact value). Partials use the reference's format:
+// mid_o = acc/sum (normalised), mid_lse = log2(sum) + max in the scaled base-2 domain
+// (paged_attn.py:106-108), so phase 1 can be compared with the reference's phase 1 directly.
+#include "swl_common.h"
+
+namespace swl {
+
+constexpr int kBlk = 16;          // tokens per KV block (engine_config.block_size)
+
+struct PagedAttnParams {
+    void *o_direct;
+    const void *q;
+    const void *k_cache;
+    const void *v_cache;
+    const int *block_table;
+    const int *seq_ids;
+    const int *seq_lens;
+    float *mid_o;
+    float *mid_lse;
+    float scale_log2e;
+    int H, KVH, L, layer, max_blocks_per_seq, seq_block_size, num_seq_blocks;
+    int64_t q_tok_stride, o_tok_stride;
+};
+
+template <typename T, int D, int G>
+struct DecodeTile {
+    static constexpr int LPT = D / 8;      // lanes per token row
+    static constexpr int TPI = 64 / LPT;   // tokens per load instruction (rows per wave)
+    static constexpr int NI = kBlk / TPI;  // load instructions per 16-token block
+};
+
+// One 16-token block for one wave. s/p live only here; m, l, acc persist.
+template <typename T, int D, int G, bool MASKED>
+__device__ __forceinline__ void attend_block(const vec8_t<T> (&qv)[G],
+                                             const vec8_t<T> (&Kv)[DecodeTile<T, D, G>::NI],
+                                             const vec8_t<T> (&Vv)[DecodeTile<T, D, G>::NI],
+                                             float (&m)[G], float (&l)[G], float (&acc)[G][8],
+                                             float c, int tok0, int row, int len) {
+    using Tile = DecodeTile<T, D, G>;
+    constexpr int NI = Tile::NI;
+    float vf[NI][8];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vf[i][j] = to_f(Vv[i][j]);
+
+    bool valid[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) valid[i] = !MASKED || (tok0 + i * Tile::TPI + row < len);
+
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float s[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            s[i] = group_allreduce_sum<Tile::LPT>(dot8<T>(qv[g], Kv[i], 0.f));
+            if (MASKED && !valid[i]) s[i] = kNegBig;
+        }
+        float m_new = m[g];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) m_new = fmaxf(m_new, s[i]);
+        const float mc = m_new * c;
+        const float alpha = fast_exp2(fmaf(m[g], c, -mc));
+        float p[NI];
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            p[i] = fast_exp2(fmaf(s[i], c, -mc));
+            if (MASKED && !valid[i]) p[i] = 0.f;
+            psum += p[i];
+        }
+        l[g] = fmaf(l[g], alpha, psum);
+        m[g] = m_new;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = acc[g][j] * alpha;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) a = fmaf(p[i], vf[i][j], a);
+            acc[g][j] = a;
+        }
+    }
+}
+
+template <typename T, int D, int G>
+__global__ __launch_bounds__(256) void paged_attn_phase1_kernel(PagedAttnParams p) {
+    using Tile = DecodeTile<T, D, G>;
+    constexpr int LPT = Tile::LPT, TPI = Tile::TPI, NI = Tile::NI;
+    __shared__ float sm_ml[4][G][2];
+    __shared__ float sm_acc[4][G][D];
+
+    const int split = blockIdx.x;
+    const int kvh = blockIdx.y;
+    const int seq = blockIdx.z;
+    const int len = p.seq_lens[seq];
+    const int tok_begin = split * p.seq_block_size;
+    if (tok_begin >= len) return; // uniform for the workgroup, before any barrier
+    const int tok_end = min(len, tok_begin + p.seq_block_size);
+    const int blk_end = (tok_end + kBlk - 1) / kBlk;
+    const int seq_id = p.seq_ids[seq];
+    const int *bt = p.block_table + static_cast<int64_t>(seq_id) * p.max_blocks_per_seq;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int chunk = lane % LPT;
+    const int row = lane / LPT;
+    const float c = p.scale_log2e;
+
+    const T *kc = static_cast<const T *>(p.k_cache);
+    const T *vc = static_cast<const T *>(p.v_cache);
+    const int64_t tile_elems = static_cast<int64_t>(kBlk) * D;
+    const int64_t layer_head = static_cast<int64_t>(p.layer) * p.KVH + kvh;
+    const int64_t blk_pitch = static_cast<int64_t>(p.L) * p.KVH;
+
+    vec8_t<T> qv[G];
+    {
+        const T *qp = static_cast<const T *>(p.q) + seq * p.q_tok_stride +
+                      static_cast<int64_t>(kvh) * G * D + chunk * 8;
+#pragma unroll
+        for (int g = 0; g < G; ++g) qv[g] = load8(qp + g * D);
+    }
+
+    float m[G], l[G], acc[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        m[g] = kNegBig;
+        l[g] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
+    }
+
+    vec8_t<T> Ka[NI], Va[NI], Kb[NI], Vb[NI];
+    auto load_block = [&](int b, vec8_t<T>(&Kr)[NI], vec8_t<T>(&Vr)[NI]) {
+        const int64_t phys = bt[b]; // scalar load: b is wave-uniform
+        const int64_t base = (phys * blk_pitch + layer_head) * tile_elems + lane * 8;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            Kr[i] = load8_nt(kc + base + i * 512);
+            Vr[i] = load8_nt(vc + base + i * 512);
+        }
+    };
+    auto attend = [&](int b, const vec8_t<T>(&Kr)[NI], const vec8_t<T>(&Vr)[NI]) {
+        const int tok0 = b * kBlk;
+        if (tok0 + kBlk > len)
+            attend_block<T, D, G, true>(qv, Kr, Vr, m, l, acc, c, tok0, row, len);
+        else
+            attend_block<T, D, G, false>(qv, Kr, Vr, m, l, acc, c, tok0, row, len);
+    };
+
+    int b = tok_begin / kBlk + wave;
+    if (b < blk_end) {
+        load_block(b, Ka, Va);
+        while (true) {
+            if (b + 4 < blk_end) load_block(b + 4, Kb, Vb);
+            attend(b, Ka, Va);
+            b += 4;
+            if (b >= blk_end) break;
+            if (b + 4 < blk_end) load_block(b + 4, Ka, Va);
+            attend(b, Kb, Vb);
+            b += 4;
+            if (b >= blk_end) break;
+        }
+    }
+
+    // ---- merge the TPI rows of this wave (each row holds tokens == row mod TPI) ----------------
+#pragma unroll
+    for (int mask = LPT; mask < 64; mask <<= 1) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float m2 = __shfl_xor(m[g], mask, 64);
+            const float l2 = __shfl_xor(l[g], mask, 64);
+            const float M = fmaxf(m[g], m2);
+            const float w1 = fast_exp2((m[g] - M) * c);
+            const float w2 = fast_exp2((m2 - M) * c);
+            l[g] = l[g] * w1 + l2 * w2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float a2 = __shfl_xor(acc[g][j], mask, 64);
+                acc[g][j] = acc[g][j] * w1 + a2 * w2;
+            }
+            m[g] = M;
+        }
+    }
+    if (row == 0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (chunk == 0) {
+                sm_ml[wave][g][0] = m[g];
+                sm_ml[wave][g][1] = l[g];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sm_acc[wave][g][chunk * 8 + j] = acc[g][j];
+        }
+    }
+    __syncthreads();
+
+    // ---- merge the 4 waves and write the partial (or the final output when there is one split) --
+    const int nsb = p.num_seq_blocks;
+    for (int oidx = threadIdx.x; oidx < G * D; oidx += 256) {
+        const int g = oidx / D;
+        const int d = oidx % D;
+        float M = sm_ml[0][g][0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) M = fmaxf(M, sm_ml[w][g][0]);
+        float Lsum = 0.f, A = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float wgt = fast_exp2((sm_ml[w][g][0] - M) * c);
+            Lsum = fmaf(sm_ml[w][g][1], wgt, Lsum);
+            A = fmaf(sm_acc[w][g][d], wgt, A);
+        }
+        const float out = A / Lsum;
+        const int head = kvh * G + g;
+        if (nsb == 1) {
+            static_cast<T *>(p.o_direct)[seq * p.o_tok_stride + static_cast<int64_t>(head) * D + d] =
+                to_t<T>(out);
+        } else {
+            const int64_t part = (static_cast<int64_t>(seq) * p.H + head) * nsb + split;
+            p.mid_o[part * D + d] = out;
+            if (d == 0) p.mid_lse[part] = fast_log2(Lsum) + M * c;
+        }
+    }
+}
+
+// grid (H, Bd), one wave per (sequence, q-head): LSE-weighted merge of the partials.
+template <typename T, int D>
+__global__ __launch_bounds__(64) void paged_attn_phase2_kernel(
+    T *__restrict__ o, const float *__restrict__ mid_o, const float *__restrict__ mid_lse,
+    const int *__restrict__ seq_lens, int H, int seq_block_size, int num_seq_blocks,
+    int64_t o_tok_stride) {
+    const int head = blockIdx.x;
+    const int seq = blockIdx.y;
+    const int lane = threadIdx.x;
+    const int len = seq_lens[seq];
+    const int n = (len + seq_block_size - 1) / seq_block_size;
+    const int64_t base = (static_cast<int64_t>(seq) * H + head) * num_seq_blocks;
+
+    float M = kNegBig;
+    for (int s = lane; s < n; s += 64) M = fmaxf(M, mid_lse[base + s]);
+    M = wave_allreduce_max(M);
+
+    constexpr int VD = (D + 63) / 64;
+    float acc[VD];
+#pragma unroll
+    for (int v = 0; v < VD; ++v) acc[v] = 0.f;
+    float Lsum = 0.f;
+    for (int s = 0; s < n; ++s) {
+        const float w = fast_exp2(mid_lse[base + s] - M);
+        Lsum += w;
+#pragma unroll
+        for (int v = 0; v < VD; ++v) {
+            const int d = lane + v * 64;
+            if (d < D) acc[v] = fmaf(w, mid_o[(base + s) * D + d], acc[v]);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < VD; ++v) {
+        const int d = lane + v * 64;
+        if (d < D) o[seq * o_tok_stride + static_cast<int64_t>(head) * D + d] = to_t<T>(acc[v] / Lsum);
+    }
+}
+
+template <typename T, int D, int G>
+static int launch_phase1(const PagedAttnParams &p, int Bd, hipStream_t stream) {
+    const dim3 grid(p.num_seq_blocks, p.KVH, Bd);
+    hipLaunchKernelGGL((paged_attn_phase1_kernel<T, D, G>), grid, dim3(256), 0, stream, p);
+    return check_launch();
+}
+
+template <typename T, int D>
+static int dispatch_phase1_g(const PagedAttnParams &p, int Bd, int G, hipStream_t stream) {
+    switch (G) {
+    case 1: return launch_phase1<T, D, 1>(p, Bd, stream);
+    case 2: return launch_phase1<T, D, 2>(p, Bd, stream);
+    case 4: return launch_phase1<T, D, 4>(p, Bd, stream);
+    case 8: return launch_phase1<T, D, 8>(p, Bd, stream);
+    default: return SWL_ERR_UNSUPPORTED;
+    }
+}
+
+template <typename T>
+static int dispatch_phase1(const PagedAttnParams &p, int Bd, int D, int G, hipStream_t stream) {
+    switch (D) {
+    case 32: return dispatch_phase1_g<T, 32>(p, Bd, G, stream);
+    case 64: return dispatch_phase1_g<T, 64>(p, Bd, G, stream);
+    case 128: return dispatch_phase1_g<T, 128>(p, Bd, G, stream);
+    default: return SWL_ERR_UNSUPPORTED;
+    }
+}
+
+template <typename T>
+static int dispatch_phase2(T *o, const float *mid_o, const float *mid_lse, const int *seq_lens,
+                           int Bd, int H, int D, int sbs, int nsb, int64_t o_tok_stride,
+                           hipStream_t stream) {
+    const dim3 grid(H, Bd);
+#define SWL_P2(DD)                                                                               \
+    hipLaunchKernelGGL((paged_attn_phase2_kernel<T, DD>), grid, dim3(64), 0, stream, o, mid_o,   \
+                       mid_lse, seq_lens, H, sbs, nsb, o_tok_stride)
+    switch (D) {
+    case 32: SWL_P2(32); break;
+    case 64: SWL_P2(64); break;
+    case 128: SWL_P2(128); break;
+    default: return SWL_ERR_UNSUPPORTED;
+    }
+#undef SWL_P2
+    return check_launch();
+}
+
+} // namespace swl
+
+extern "C" size_t swl_paged_attn_scratch_bytes(int32_t num_decoding_seqs, int32_t num_q_heads,
+                                               int32_t head_dim, int32_t num_seq_blocks) {
+    if (num_decoding_seqs <= 0 || num_q_heads <= 0 || head_dim <= 0 || num_seq_blocks <= 0) return 0;
+    const size_t parts = static_cast<size_t>(num_decoding_seqs) * num_q_heads * num_seq_blocks;
+    return parts * (static_cast<size_t>(head_dim) + 1) * sizeof(float);
+}
+
+extern "C" int swl_paged_attn_phase1(void *o_direct, const void *q, const void *k_cache,
+                                     const void *v_cache, const int32_t *block_table,
+                                     const int32_t *seq_ids, const int32_t *seq_lens, float *mid_o,
+                                     float *mid_lse, float softmax_scale, int32_t num_decoding_seqs,
+                                     int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
+                                     int32_t num_layers, int32_t block_size, int32_t cur_layer,
+                                     int32_t max_blocks_per_seq, int32_t seq_block_size,
+                                     int32_t num_seq_blocks, int64_t q_tok_stride,
+                                     int64_t o_tok_stride, int32_t dtype, swl_stream_t stream) {
+    if (num_decoding_seqs < 0) return SWL_ERR_BAD_ARG;
+    if (num_decoding_seqs == 0 || num_seq_blocks == 0) return SWL_OK;
+    if (!q || !k_cache || !v_cache || !block_table || !seq_ids || !seq_lens) return SWL_ERR_BAD_ARG;
+    if (num_seq_blocks < 0 || num_q_heads <= 0 || num_kv_heads <= 0 ||
+        num_q_heads % num_kv_heads != 0 || num_layers <= 0 || cur_layer < 0 ||
+        cur_layer >= num_layers || max_blocks_per_seq <= 0)
+        return SWL_ERR_BAD_ARG;
+    if (block_size != swl::kBlk) return SWL_ERR_UNSUPPORTED;
+    if (seq_block_size <= 0 || seq_block_size % block_size != 0) return SWL_ERR_BAD_ARG;
+    if (num_seq_blocks == 1 ? !o_direct : (!mid_o || !mid_lse)) return SWL_ERR_BAD_ARG;
+    if (!swl::aligned16(q) || !swl::aligned16(k_cache) || !swl::aligned16(v_cache) ||
+        (q_tok_stride & 7))
+        return SWL_ERR_BAD_ARG;
+    if (num_decoding_seqs > 65535 || num_kv_heads > 65535) return SWL_ERR_UNSUPPORTED;
+    swl::PagedAttnParams p;
+    p.o_direct = o_direct;
+    p.q = q;
+    p.k_cache = k_cache;
+    p.v_cache = v_cache;
+    p.block_table = block_table;
+    p.seq_ids = seq_ids;
+    p.seq_lens = seq_lens;
+    p.mid_o = mid_o;
+    p.mid_lse = mid_lse;
+    p.scale_log2e = softmax_scale * 1.44269504088896340736f;
+    p.H = num_q_heads;
+    p.KVH = num_kv_heads;
+    p.L = num_layers;
+    p.layer = cur_layer;
+    p.max_blocks_per_seq = max_blocks_per_seq;
+    p.seq_block_size = seq_block_size;
+    p.num_seq_blocks = num_seq_blocks;
+    p.q_tok_stride = q_tok_stride;
+    p.o_tok_stride = o_tok_stride;
+    const int G = num_q_heads / num_kv_heads;
+    SWL_DISPATCH_DTYPE(dtype, T, {
+        return swl::dispatch_phase1<T>(p, num_decoding_seqs, head_dim, G,
+                                       static_cast<hipStream_t>(stream));
+    });
+}
+
+extern "C" int swl_paged_attn_phase2(void *o, const float *mid_o, const float *mid_lse,
+                                     const int32_t *seq_lens, int32_t num_decoding_seqs,
+                                     int32_t num_q_heads, int32_t head_dim, int32_t seq_block_size,
+                                     int32_t num_seq_blocks, int64_t o_tok_stride, int32_t dtype,
+                                     swl_stream_t stream) {
+    if (num_decoding_seqs < 0) return SWL_ERR_BAD_ARG;
+    if (num_decoding_seqs == 0 || num_seq_blocks == 0) return SWL_OK;
+    if (!o || !mid_o || !mid_lse || !seq_lens || num_q_heads <= 0 || seq_block_size <= 0 ||
+        num_seq_blocks < 0)
+        return SWL_ERR_BAD_ARG;
+    if (num_decoding_seqs > 65535) return SWL_ERR_UNSUPPORTED;
+    SWL_DISPATCH_DTYPE(dtype, T, {
+        return swl::dispatch_phase2<T>(static_cast<T *>(o), mid_o, mid_lse, seq_lens,
+                                       num_decoding_seqs, num_q_heads, head_dim, seq_block_size,
+                                       num_seq_blocks, o_tok_stride,
+                                       static_cast<hipStream_t>(stream));
+    });
+}
+
+extern "C" int swl_paged_attn_decode(void *o, const void *q, const void *k_cache,
+                                     const void *v_cache, const int32_t *block_table,
+                                     const int32_t *seq_ids, const int32_t *seq_lens, void *scratch,
+                                     float softmax_scale, int32_t num_decoding_seqs,
+                                     int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
+                                     int32_t num_layers, int32_t block_size, int32_t cur_layer,
+                                     int32_t max_blocks_per_seq, int32_t seq_block_size,
+                                     int32_t num_seq_blocks, int64_t q_tok_stride,
+                                     int64_t o_tok_stride, int32_t dtype, swl_stream_t stream) {
+    if (num_decoding_seqs < 0) return SWL_ERR_BAD_ARG;
+    if (num_decoding_seqs == 0 || num_seq_blocks == 0) return SWL_OK;
+    if (!o) return SWL_ERR_BAD_ARG;
+    float *mid_o = nullptr, *mid_lse = nullptr;
+    if (num_seq_blocks > 1) {
+        if (!scratch || !swl::aligned16(scratch)) return SWL_ERR_BAD_ARG;
+        mid_o = static_cast<float *>(scratch);
+        mid_lse = mid_o + static_cast<size_t>(num_decoding_seqs) * num_q_heads * num_seq_blocks *
+                              head_dim;
+    }
+    int rc = swl_paged_attn_phase1(o, q, k_cache, v_cache, block_table, seq_ids, seq_lens, mid_o,
+                                   mid_lse, softmax_scale, num_decoding_seqs, num_q_heads,
+                                   num_kv_heads, head_dim, num_layers, block_size, cur_layer,
+                                   max_blocks_per_seq, seq_block_size, num_seq_blocks, q_tok_stride,
+                                   o_tok_stride, dtype, stream);
+    if (rc != SWL_OK || num_seq_blocks == 1) return rc;
+    return swl_paged_attn_phase2(o, mid_o, mid_lse, seq_lens, num_decoding_seqs, num_q_heads,
+                                 head_dim, seq_block_size, num_seq_blocks, o_tok_stride, dtype,
+                                 stream);
+}

@@ -1,0 +1,157 @@
+// swl_common.h — device-side helpers shared by the gfx950 kernels of libswiftllm_hip.so.
+// CDNA4 only: wave = 64 lanes, 16-byte (8 x 16-bit) vector accesses everywhere, DPP row reductions.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/swiftllm_hip.h"
+
+namespace swl {
+
+using f16 = _Float16;
+using bf16 = __bf16;
+
+constexpr int kWave = 64;
+// Finite stand-in for -inf in online-softmax running maxima: (-inf) - (-inf) would be NaN.
+constexpr float kNegBig = -1e30f;
+
+// 8 x 16-bit elements = one 16-byte global/LDS access per lane.
+template <typename T>
+struct Vec8 {
+    typedef T type __attribute__((ext_vector_type(8)));
+};
+template <typename T>
+using vec8_t = typename Vec8<T>::type;
+template <typename T>
+struct Vec2 {
+    typedef T type __attribute__((ext_vector_type(2)));
+};
+template <typename T>
+using vec2_t = typename Vec2<T>::type;
+
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+
+template <typename T>
+__device__ __forceinline__ vec8_t<T> load8(const T *p) {
+    return *reinterpret_cast<const vec8_t<T> *>(p);
+}
+template <typename T>
+__device__ __forceinline__ void store8(T *p, vec8_t<T> v) {
+    *reinterpret_cast<vec8_t<T> *>(p) = v;
+}
+// Streaming (read-once) 16-byte load: bypasses nothing semantically, just marks the line
+// non-temporal so KV-pool / weight streams do not evict reusable lines.
+template <typename T>
+__device__ __forceinline__ vec8_t<T> load8_nt(const T *p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const vec8_t<T> *>(p));
+}
+
+// Round-to-nearest-even conversion float -> T (v_cvt_f16_f32 / v_cvt_pk_bf16_f32 on gfx950).
+template <typename T>
+__device__ __forceinline__ T to_t(float x) {
+    return static_cast<T>(x);
+}
+template <typename T>
+__device__ __forceinline__ float to_f(T x) {
+    return static_cast<float>(x);
+}
+
+// Arithmetic "in T": one rounding to T per operation, never contracted to fma.
+// (fp16*fp16 and bf16*bf16 are exact in fp32, so rounding the fp32 product is the correctly
+// rounded T product; sums are rounded once from the fp32 sum.)
+template <typename T>
+__device__ __forceinline__ T mul_t(T a, T b) {
+    float r = __fmul_rn(to_f(a), to_f(b));
+    return to_t<T>(r);
+}
+template <typename T>
+__device__ __forceinline__ T add_t(T a, T b) {
+    float r = __fadd_rn(to_f(a), to_f(b));
+    return to_t<T>(r);
+}
+template <typename T>
+__device__ __forceinline__ T sub_t(T a, T b) {
+    float r = __fsub_rn(to_f(a), to_f(b));
+    return to_t<T>(r);
+}
+
+// 2-element dot product with fp32 accumulate: v_dot2c_f32_f16 / v_dot2c_f32_bf16.
+__device__ __forceinline__ float dot2(vec2_t<f16> a, vec2_t<f16> b, float c) {
+    return __builtin_amdgcn_fdot2(a, b, c, false);
+}
+__device__ __forceinline__ float dot2(vec2_t<bf16> a, vec2_t<bf16> b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false);
+}
+template <typename T>
+__device__ __forceinline__ float dot8(vec8_t<T> a, vec8_t<T> b, float c) {
+    c = dot2(vec2_t<T>{a[0], a[1]}, vec2_t<T>{b[0], b[1]}, c);
+    c = dot2(vec2_t<T>{a[2], a[3]}, vec2_t<T>{b[2], b[3]}, c);
+    c = dot2(vec2_t<T>{a[4], a[5]}, vec2_t<T>{b[4], b[5]}, c);
+    c = dot2(vec2_t<T>{a[6], a[7]}, vec2_t<T>{b[6], b[7]}, c);
+    return c;
+}
+
+// ---- DPP cross-lane helpers (no LDS traffic) ----------------------------------------------------
+constexpr int kDppQuadXor1 = 0xB1;       // quad_perm:[1,0,3,2]
+constexpr int kDppQuadXor2 = 0x4E;       // quad_perm:[2,3,0,1]
+constexpr int kDppRowHalfMirror = 0x141; // lane j <-> 7-j inside each 8 lanes
+constexpr int kDppRowMirror = 0x140;     // lane j <-> 15-j inside each 16 lanes
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(
+        __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+// All-reduce (sum) over aligned groups of N lanes, N in {1,2,4,8,16}: every lane ends with the total.
+template <int N>
+__device__ __forceinline__ float group_allreduce_sum(float v) {
+    if constexpr (N >= 2) v += dpp_mov<kDppQuadXor1>(v);
+    if constexpr (N >= 4) v += dpp_mov<kDppQuadXor2>(v);
+    if constexpr (N >= 8) v += dpp_mov<kDppRowHalfMirror>(v);
+    if constexpr (N >= 16) v += dpp_mov<kDppRowMirror>(v);
+    return v;
+}
+
+// Full-wave (64-lane) all-reduce: DPP inside rows of 16, then two cross-row exchanges.
+__device__ __forceinline__ float wave_allreduce_sum(float v) {
+    v = group_allreduce_sum<16>(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_allreduce_max(float v) {
+    v = fmaxf(v, dpp_mov<kDppQuadXor1>(v));
+    v = fmaxf(v, dpp_mov<kDppQuadXor2>(v));
+    v = fmaxf(v, dpp_mov<kDppRowHalfMirror>(v));
+    v = fmaxf(v, dpp_mov<kDppRowMirror>(v));
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
+// exp2 on the hardware transcendental unit (v_exp_f32 IS 2^x).
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+
+inline int check_launch() { return hipGetLastError() == hipSuccess ? SWL_OK : SWL_ERR_LAUNCH; }
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+} // namespace swl
+
+// Dispatch a templated launcher on the runtime dtype code.
+#define SWL_DISPATCH_DTYPE(dtype, T, ...)            \
+    do {                                             \
+        if ((dtype) == SWL_F16) {                    \
+            using T = swl::f16;                      \
+            __VA_ARGS__                              \
+        } else if ((dtype) == SWL_BF16) {            \
+            using T = swl::bf16;                     \
+            __VA_ARGS__                              \
+        } else {                                     \
+            return SWL_ERR_BAD_ARG;                  \
+        }                                            \
+    } while (0)

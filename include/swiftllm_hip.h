@@ -155,11 +155,14 @@ int swl_prefill_attn_varlen(void *o, const void *q, const void *k, const void *v
  * block_table int32 [max_seqs, max_blocks_per_seq]; num_seq_allocated_blocks int32 [max_seqs];
  * is_block_free uint8(bool) [num_blocks].
  * set: for batch entry i (seq s): block_table[s, n_s : n_s + need_i] = candidates[off_i : off_i + need_i],
- *      n_s += need_i, where off = exclusive cumsum(block_needed) (passed in by the caller). */
+ *      n_s += need_i, where off = exclusive cumsum(block_needed) (passed in by the caller).
+ *      If is_block_free != NULL the candidates are also marked used (is_block_free[c] = 0), which
+ *      fuses the reference's separate scatter at block_manager.py:52. */
 int swl_block_table_set(int32_t *num_seq_allocated_blocks, int32_t *block_table,
                         const int32_t *candidate_blocks, const int32_t *seq_ids,
                         const int32_t *block_needed, const int32_t *block_needed_excl_cumsum,
-                        int32_t batch_size, int32_t max_blocks_per_seq, swl_stream_t stream);
+                        uint8_t *is_block_free, int32_t batch_size, int32_t max_blocks_per_seq,
+                        swl_stream_t stream);
 /* unset: is_block_free[block_table[s, 0:n_s]] = 1; n_s = 0. */
 int swl_block_table_unset(int32_t *num_seq_allocated_blocks, const int32_t *block_table,
                           const int32_t *seq_ids, uint8_t *is_block_free, int32_t batch_size,

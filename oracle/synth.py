@@ -1,0 +1,77 @@
+"""oracle/synth.py — synthetic LLaMA checkpoints (TEST INFRASTRUCTURE).
+
+There are no real weights on disk and no network, so every test and bench runs on random-init models
+written by this helper: an HF-style config.json plus one safetensors file, seeded, matrices
+~ N(0, 0.02^2), norm weights = 1 + N(0, 0.02^2) (the reference's own dummy init
+U(-1e-3, 1e-3), weight.py:217, makes every logit ~0 and argmax meaningless).
+"""
+import json
+import os
+
+import torch
+
+# BASELINE.json configs[0]: 2-layer / 128-dim LLaMA
+TINY = dict(num_hidden_layers=2, hidden_size=128, num_attention_heads=4, num_key_value_heads=2,
+            intermediate_size=256, vocab_size=256, max_position_embeddings=512)
+# same width, head_dim 64 / 128 variants for kernel-shape coverage
+SMALL64 = dict(num_hidden_layers=2, hidden_size=256, num_attention_heads=4, num_key_value_heads=2,
+               intermediate_size=512, vocab_size=512, max_position_embeddings=1024)
+SMALL128 = dict(num_hidden_layers=2, hidden_size=512, num_attention_heads=4, num_key_value_heads=1,
+                intermediate_size=1024, vocab_size=512, max_position_embeddings=2048)
+LLAMA3_8B = dict(num_hidden_layers=32, hidden_size=4096, num_attention_heads=32,
+                 num_key_value_heads=8, intermediate_size=14336, vocab_size=128256,
+                 max_position_embeddings=8192, rope_theta=500000.0, rms_norm_eps=1e-5)
+LLAMA2_7B = dict(num_hidden_layers=32, hidden_size=4096, num_attention_heads=32,
+                 num_key_value_heads=32, intermediate_size=11008, vocab_size=32000,
+                 max_position_embeddings=4096, rope_theta=10000.0, rms_norm_eps=1e-5)
+
+
+def make_config(**overrides) -> dict:
+    cfg = dict(model_type="llama", hidden_act="silu", rms_norm_eps=1e-5, rope_theta=10000.0,
+               rope_scaling=None, tie_word_embeddings=False)
+    cfg.update(TINY)
+    cfg.update(overrides)
+    return cfg
+
+
+def make_state_dict(cfg: dict, seed: int = 0, dtype=torch.float16, std: float = 0.02) -> dict:
+    g = torch.Generator().manual_seed(seed)
+    h, inter, v = cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"]
+    kv = cfg.get("num_key_value_heads", cfg["num_attention_heads"]) * (h // cfg["num_attention_heads"])
+
+    def mat(*shape):
+        return (torch.randn(*shape, generator=g) * std).to(dtype)
+
+    def norm(n):
+        return (1.0 + torch.randn(n, generator=g) * std).to(dtype)
+
+    sd = {"model.embed_tokens.weight": mat(v, h), "lm_head.weight": mat(v, h),
+          "model.norm.weight": norm(h)}
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"model.layers.{i}."
+        sd[p + "input_layernorm.weight"] = norm(h)
+        sd[p + "self_attn.q_proj.weight"] = mat(h, h)
+        sd[p + "self_attn.k_proj.weight"] = mat(kv, h)
+        sd[p + "self_attn.v_proj.weight"] = mat(kv, h)
+        sd[p + "self_attn.o_proj.weight"] = mat(h, h)
+        sd[p + "post_attention_layernorm.weight"] = norm(h)
+        sd[p + "mlp.up_proj.weight"] = mat(inter, h)
+        sd[p + "mlp.gate_proj.weight"] = mat(inter, h)
+        sd[p + "mlp.down_proj.weight"] = mat(h, inter)
+    return sd
+
+
+def write_model_dir(path: str, cfg: dict, state_dict: dict = None, fmt: str = "safetensors"):
+    """config.json (+ weights) in `path`. state_dict=None writes the config only (use_dummy runs)."""
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, "config.json"), "w", encoding="utf-8") as f:
+        json.dump(cfg, f)
+    if state_dict is None:
+        return path
+    if fmt == "safetensors":
+        from safetensors.torch import save_file
+        save_file({k: v.contiguous() for k, v in state_dict.items()},
+                  os.path.join(path, "model.safetensors"))
+    else:
+        torch.save(state_dict, os.path.join(path, "pytorch_model.bin"))
+    return path

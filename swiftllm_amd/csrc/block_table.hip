@@ -14,14 +14,18 @@ namespace swl {
 __global__ __launch_bounds__(64) void block_table_set_kernel(
     int *__restrict__ num_alloc, int *__restrict__ block_table, const int *__restrict__ candidates,
     const int *__restrict__ seq_ids, const int *__restrict__ need, const int *__restrict__ need_off,
-    int max_blocks_per_seq) {
+    uint8_t *__restrict__ is_block_free, int max_blocks_per_seq) {
     const int i = blockIdx.x;
     const int64_t s = seq_ids[i];
     const int n = need[i];
     const int off = need_off[i];
     const int have = num_alloc[s];
     int *row = block_table + s * max_blocks_per_seq + have;
-    for (int j = threadIdx.x; j < n; j += 64) row[j] = candidates[off + j];
+    for (int j = threadIdx.x; j < n; j += 64) {
+        const int b = candidates[off + j];
+        row[j] = b;
+        if (is_block_free) is_block_free[b] = 0;
+    }
     __syncthreads(); // every lane has read `have` before lane 0 overwrites it
     if (threadIdx.x == 0) num_alloc[s] = have + n;
 }
@@ -50,7 +54,8 @@ __global__ __launch_bounds__(64) void block_table_unset_kernel(
 extern "C" int swl_block_table_set(int32_t *num_seq_allocated_blocks, int32_t *block_table,
                                    const int32_t *candidate_blocks, const int32_t *seq_ids,
                                    const int32_t *block_needed,
-                                   const int32_t *block_needed_excl_cumsum, int32_t batch_size,
+                                   const int32_t *block_needed_excl_cumsum,
+                                   uint8_t *is_block_free, int32_t batch_size,
                                    int32_t max_blocks_per_seq, swl_stream_t stream) {
     if (batch_size < 0 || max_blocks_per_seq <= 0) return SWL_ERR_BAD_ARG;
     if (batch_size == 0) return SWL_OK;
@@ -60,7 +65,7 @@ extern "C" int swl_block_table_set(int32_t *num_seq_allocated_blocks, int32_t *b
     hipLaunchKernelGGL(swl::block_table_set_kernel, dim3(batch_size), dim3(64), 0,
                        static_cast<hipStream_t>(stream), num_seq_allocated_blocks, block_table,
                        candidate_blocks, seq_ids, block_needed, block_needed_excl_cumsum,
-                       max_blocks_per_seq);
+                       is_block_free, max_blocks_per_seq);
     return swl::check_launch();
 }
 

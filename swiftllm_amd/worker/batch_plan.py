@@ -1,0 +1,119 @@
+"""Host-side batch planning: everything `LlamaModel.forward` derives from its Python-list arguments
+before touching the device. Pure numpy — unit-tested on CPU against the reference's arithmetic.
+
+Reference: swiftllm/worker/model.py:268-324 (flattening, sequence lengths, start offsets, position
+indices, the seq_block_size heuristic) and post_layer.py:24-29 (last-token indices).
+"""
+import dataclasses
+import itertools
+from typing import List, Sequence
+
+import numpy as np
+
+
+def select_seq_block_size(decoding_seq_lens: Sequence[int], num_kv_heads: int,
+                          target_workgroups: int = 1024, min_size: int = 64,
+                          max_blocks_per_seq: int = 128) -> int:
+    """Split-K width (tokens) of flash-decoding.
+
+    Same search as the reference (model.py:305-324): start at 2048 and halve while the launch would
+    have fewer than `target_workgroups` useful workgroups, the width stays >= min_size and no
+    sequence is cut into more than `max_blocks_per_seq` pieces. Our phase-1 workgroup serves a whole
+    kv-head group, so useful workgroups = KVH * sum(len)/width — numerically the reference's
+    formula; `target_workgroups` = 4 x the CU count (256 on MI355X: 2 co-resident workgroups per CU,
+    two rounds) replaces its "1024 because ~128 SMs" magic number.
+    """
+    size = 2048
+    total = sum(decoding_seq_lens)
+    longest = max(decoding_seq_lens) if len(decoding_seq_lens) else 0
+    while (num_kv_heads * (total / size) < target_workgroups and size // 2 >= min_size
+           and longest / (size // 2) <= max_blocks_per_seq):
+        size //= 2
+    return size
+
+
+@dataclasses.dataclass
+class BatchPlan:
+    batch_size: int
+    num_tokens: int
+    num_prefill_seqs: int
+    num_prefill_tokens: int
+    max_prefill_len: int
+    num_decoding_seqs: int
+    max_decoding_len: int
+    seq_block_size: int
+    num_seq_blocks: int
+    seq_lengths_list: List[int]
+    # int32 arrays
+    input_ids: np.ndarray               # [T]
+    seq_ids: np.ndarray                 # [B]
+    seq_lengths: np.ndarray             # [B]
+    prefill_seq_lens: np.ndarray        # [Bp]
+    prefill_start_locs_with_end: np.ndarray  # [Bp + 1]
+    decoding_seq_lens: np.ndarray       # [Bd]
+    position_indices: np.ndarray        # [T]
+    last_token_indices: np.ndarray      # [B]
+
+    SEGMENTS = ("input_ids", "seq_ids", "seq_lengths", "prefill_seq_lens",
+                "prefill_start_locs_with_end", "decoding_seq_lens", "position_indices",
+                "last_token_indices")
+
+    def packed_layout(self):
+        """(name, offset, size) of every array inside one int32 buffer; offsets are multiples of 4
+        elements (16 bytes). The layout depends only on (T, B, Bp), so a replayed hipGraph of a
+        pure-decode batch of size B always finds its metadata at the same addresses."""
+        out, off = [], 0
+        for name in self.SEGMENTS:
+            n = getattr(self, name).size
+            out.append((name, off, n))
+            off += (n + 3) // 4 * 4
+        return out, off
+
+    def pack_into(self, buf: np.ndarray) -> int:
+        layout, total = self.packed_layout()
+        for name, off, n in layout:
+            buf[off:off + n] = getattr(self, name)
+        return total
+
+
+def plan_batch(input_ids_list: Sequence[Sequence[int]], seq_ids_list: Sequence[int],
+               decoding_seq_lens_list: Sequence[int], num_kv_heads: int,
+               target_workgroups: int = 1024) -> BatchPlan:
+    """Prefill sequences come first in all three lists (reference model.py:268-270); a decoding
+    sequence contributes exactly one token and its length INCLUDES that token."""
+    batch_size = len(input_ids_list)
+    num_decoding = len(decoding_seq_lens_list)
+    num_prefill = batch_size - num_decoding
+    if num_prefill < 0 or len(seq_ids_list) != batch_size:
+        raise ValueError("inconsistent batch: need len(seq_ids) == len(input_ids) >= len(decoding_seq_lens)")
+    prefill_lens = [len(ids) for ids in input_ids_list[:num_prefill]]
+    flat = np.fromiter(itertools.chain.from_iterable(input_ids_list), dtype=np.int32)
+    num_tokens = flat.size
+    num_prefill_tokens = sum(prefill_lens)
+    if num_tokens - num_prefill_tokens != num_decoding:
+        raise ValueError("every decoding sequence must contribute exactly one token")
+    pl = np.asarray(prefill_lens, dtype=np.int32)
+    dl = np.asarray(decoding_seq_lens_list, dtype=np.int32)
+    starts_with_end = np.zeros(num_prefill + 1, dtype=np.int32)
+    np.cumsum(pl, out=starts_with_end[1:])
+    pos = np.empty(num_tokens, dtype=np.int32)
+    if num_prefill_tokens:
+        # 0..len-1 for every prefill sequence: global arange minus each token's sequence start
+        pos[:num_prefill_tokens] = (np.arange(num_prefill_tokens, dtype=np.int32)
+                                    - np.repeat(starts_with_end[:-1], pl))
+    pos[num_prefill_tokens:] = dl - 1
+    last = np.concatenate((starts_with_end[1:] - 1,
+                           np.arange(num_prefill_tokens, num_tokens, dtype=np.int32))).astype(np.int32)
+    sbs = select_seq_block_size(decoding_seq_lens_list, num_kv_heads, target_workgroups)
+    max_dec = max(decoding_seq_lens_list) if num_decoding else 0
+    seq_lengths_list = prefill_lens + list(decoding_seq_lens_list)
+    return BatchPlan(
+        batch_size=batch_size, num_tokens=num_tokens, num_prefill_seqs=num_prefill,
+        num_prefill_tokens=num_prefill_tokens,
+        max_prefill_len=max(prefill_lens) if prefill_lens else 0,
+        num_decoding_seqs=num_decoding, max_decoding_len=max_dec, seq_block_size=sbs,
+        num_seq_blocks=(max_dec + sbs - 1) // sbs, seq_lengths_list=seq_lengths_list,
+        input_ids=flat, seq_ids=np.asarray(seq_ids_list, dtype=np.int32),
+        seq_lengths=np.asarray(seq_lengths_list, dtype=np.int32), prefill_seq_lens=pl,
+        prefill_start_locs_with_end=starts_with_end, decoding_seq_lens=dl, position_indices=pos,
+        last_token_indices=last)

@@ -1,0 +1,42 @@
+"""Decode-stage paged attention operator. Reference: swiftllm/worker/kernels/paged_attn.py:152-222."""
+import torch
+
+from swiftllm_amd import _hip
+from ._layout import token_stride
+
+
+def paged_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                    block_table: torch.Tensor, model_config, engine_config, infer_state,
+                    cur_layer: int, o: torch.Tensor):
+    """Flash-decoding over the paged KV pool for the decoding sequences of this batch.
+
+    q, o: [num_decoding_seqs, num_q_heads, head_dim] (o may be given as [seqs, hidden]).
+    `infer_state.seq_block_size / num_seq_blocks` pick the split-K width exactly as in the
+    reference; the fp32 partials use the reference's shapes and format. A preallocated scratch
+    (`infer_state.paged_attn_scratch`) is used when present, else one is taken from torch's caching
+    allocator as the reference does (paged_attn.py:170-180).
+    """
+    _hip.require_gpu_tensor(q, "q")
+    nd = infer_state.num_decoding_seqs
+    if nd == 0:
+        return
+    assert k_cache.is_contiguous() and v_cache.is_contiguous() and block_table.is_contiguous()
+    assert infer_state.seq_block_size % engine_config.block_size == 0
+    assert q.dtype == k_cache.dtype == v_cache.dtype == o.dtype
+    if o.dim() == 2:
+        o = o.view(o.shape[0], model_config.num_q_heads, model_config.head_dim)
+    nsb = infer_state.num_seq_blocks
+    scratch = None
+    if nsb > 1:
+        need = _hip.scratch_bytes(nd, model_config.num_q_heads, model_config.head_dim, nsb)
+        scratch = getattr(infer_state, "paged_attn_scratch", None)
+        if scratch is None or scratch.numel() * scratch.element_size() < need:
+            scratch = torch.empty(need // 4, dtype=torch.float32, device=q.device)
+    _hip.call("swl_paged_attn_decode", _hip.ptr(o), _hip.ptr(q), _hip.ptr(k_cache),
+              _hip.ptr(v_cache), _hip.ptr(block_table),
+              _hip.ptr(infer_state.seq_ids[infer_state.num_prefill_seqs:]),
+              _hip.ptr(infer_state.decoding_seq_lens), _hip.ptr(scratch), infer_state.softmax_scale,
+              nd, model_config.num_q_heads, model_config.num_kv_heads, model_config.head_dim,
+              model_config.num_layers, engine_config.block_size, cur_layer, block_table.shape[1],
+              infer_state.seq_block_size, nsb, token_stride(q, "q"), token_stride(o, "o"),
+              _hip.dtype_code(q.dtype), _hip.stream())

@@ -1,0 +1,28 @@
+"""Final norm, lm_head and greedy sampling. Reference: swiftllm/worker/layers/post_layer.py:9-40."""
+import torch
+
+from ..kernels.rmsnorm import rmsnorm_inplace
+from ..kernels.linear import linear
+
+
+class LlamaPostLayer:
+    def __init__(self, model_config, weights):
+        self.model_config = model_config
+        self.weights = weights
+        self.logits_tap = None  # tests set this to a list to capture the pre-argmax logits
+
+    def forward(self, input_embds: torch.Tensor, infer_state) -> torch.Tensor:
+        """[num_tokens, hidden] -> next-token ids int64 [batch_size] (argmax; ties -> lowest id)."""
+        idx = infer_state.last_token_indices
+        if idx is None:
+            # the last token of each prefill sequence, then every decoding token
+            idx = torch.cat((
+                infer_state.prefill_seq_start_locs + infer_state.prefill_seq_lens - 1,
+                torch.arange(infer_state.num_prefill_tokens, infer_state.num_tokens,
+                             device=input_embds.device, dtype=torch.int32)))
+        last_input = input_embds.index_select(0, idx)    # fresh [batch, hidden] copy
+        rmsnorm_inplace(last_input, self.weights.final_norm, self.model_config.rms_norm_eps)
+        logits = linear(last_input, self.weights.lm_head)   # [batch, vocab]
+        if self.logits_tap is not None:
+            self.logits_tap.append(logits.float().cpu())
+        return torch.argmax(logits, dim=1)

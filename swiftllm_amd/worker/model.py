@@ -1,0 +1,327 @@
+"""LlamaModel — the data-plane worker: weights, rope tables, paged KV pools, and `forward`.
+
+Public surface and call protocol are the reference's (swiftllm/worker/model.py:18-408):
+
+    model = LlamaModel(engine_config); model.load_weights()
+    n = model.profile_num_blocks(); model.init_kvcache_and_swap(n)
+    tokens = model.forward(input_ids_list, seq_ids_list, decoding_seq_lens_list)
+    model.swap_in_seqs(ids) / model.swap_out_seqs(ids) / model.free_seqs_resources(ids)
+
+so examples/offline.py and the Engine drive it unchanged. Inside, the host side is built for MI355X:
+  * all per-forward metadata is planned with numpy (batch_plan.py), packed into ONE pinned buffer and
+    shipped with ONE async H2D copy (the reference issues ~10 small synchronous `torch.tensor(...,
+    device="cuda")` copies, model.py:272-297);
+  * block allocation is decided on a host mirror (block_manager.py): no device sync in `forward`
+    except the final D2H of the sampled tokens;
+  * rope rows are looked up inside the rotary kernel (no cos/sin gather launches);
+  * pure-decode forwards can be captured into hipGraphs, one per batch size, and replayed
+    (`EngineConfig.use_hip_graph`): ~400 launches per step collapse into one graph launch;
+  * KV pools, block tables and scheduler defaults are sized from the 288 GB of one MI355X.
+The compute backend is libswiftllm_hip.so only; without a HIP device this class raises.
+"""
+import math
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from swiftllm_amd import _hip
+from swiftllm_amd.engine_config import EngineConfig
+from swiftllm_amd.model_config import LlamaModelConfig
+from swiftllm_amd.utils import GB
+
+from .batch_plan import BatchPlan, plan_batch
+from .block_manager import BlockManager
+from .infer_state import LlamaInferState
+from .kernels.block_swapping import swap_blocks
+from .layers.pre_layer import LlamaPreLayer
+from .layers.transformer_layer import LlamaTransformerLayer
+from .layers.post_layer import LlamaPostLayer
+from .weight import load_weights
+
+_DTYPES = {"float16": torch.float16, "fp16": torch.float16, "half": torch.float16,
+           "bfloat16": torch.bfloat16, "bf16": torch.bfloat16}
+
+
+def _require_hip_device():
+    if not torch.cuda.is_available():
+        raise _hip.HipLibraryError(
+            "no HIP device visible: swiftllm_amd's data plane runs only on an AMD GPU (gfx950) "
+            "through libswiftllm_hip.so; there is no CPU path")
+    _hip.load()
+
+
+class _DecodeGraph:
+    """A captured pure-decode forward for one batch size."""
+    __slots__ = ("graph", "out_tokens", "seq_block_size", "num_seq_blocks")
+
+
+class LlamaModel:
+    """A LLaMA model resident on one GPU, driven by the control plane (or directly, offline)."""
+
+    @torch.inference_mode()
+    def __init__(self, engine_config: EngineConfig):
+        self.engine_config = engine_config
+        self.model_config = LlamaModelConfig.load_from_model_path(engine_config.model_path)
+        self.dtype = _DTYPES[getattr(engine_config, "dtype", "float16")]
+        self.device = torch.device("cuda")
+
+        self.weight = None
+        self._cos_cached = self._sin_cached = None
+        self.pre_layer = None
+        self.transformer_layers = None
+        self.post_layer = None
+
+        self.num_blocks = None
+        self.k_cache = self.v_cache = None
+        self.k_swap = self.v_swap = None
+        self.cpu_block_manager = self.gpu_block_manager = None
+
+        self._meta_host = None      # pinned int32 staging for per-forward metadata
+        self._meta_host_np = None
+        self._meta_dev = None       # its device twin (fixed address: hipGraph replays read it)
+        self._meta_done = None
+        self._target_workgroups = 1024
+        self._decode_graphs = {}
+        self._scratch = None
+
+    # ------------------------------------------------------------------------------------------------
+    @torch.inference_mode()
+    def load_weights(self):
+        """Load (or synthesise) the weights, build the rope tables and the layer objects."""
+        _require_hip_device()
+        self.weight = load_weights(self.model_config, self.dtype, self.engine_config.model_path,
+                                   self.engine_config.use_dummy, device=self.device,
+                                   fuse_qkv=getattr(self.engine_config, "fuse_qkv", False))
+        self._init_to_get_rotary()
+        self._target_workgroups = 4 * torch.cuda.get_device_properties(self.device).multi_processor_count
+        side_stream = torch.cuda.Stream()
+        self.pre_layer = LlamaPreLayer(self.model_config, self.weight)
+        self.transformer_layers = [
+            LlamaTransformerLayer(self.model_config, self.engine_config, self.weight.layers[i],
+                                  side_stream, i)
+            for i in range(self.model_config.num_layers)
+        ]
+        self.post_layer = LlamaPostLayer(self.model_config, self.weight)
+
+    @torch.inference_mode()
+    def profile_num_blocks(self) -> int:
+        """How many KV blocks fit: run a forged worst-case prefill without touching the KV cache,
+        read the device's high-water mark, give the rest (up to gpu_mem_utilization) to the pool.
+        Reference: model.py:94-131."""
+        ecfg = self.engine_config
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        num_tokens, batch = ecfg.max_tokens_in_batch, ecfg.max_batch_size
+        lens = [num_tokens // batch] * batch
+        lens[-1] += num_tokens % batch
+        self.k_cache = self.v_cache = None
+        self.forward([[0] * n for n in lens], list(range(batch)), [], ignore_kvcache=True)
+        torch.cuda.synchronize()
+        free_memory, total_memory = torch.cuda.mem_get_info()
+        peak_memory = total_memory - free_memory
+        usable = total_memory * ecfg.gpu_mem_utilization
+        print(f"[Model.profile] GPU total memory: {total_memory / GB:.2f} GB, "
+              f"runtime peak memory: {peak_memory / GB:.2f} GB")
+        if usable < peak_memory:
+            raise RuntimeError(
+                f"Peak memory {peak_memory / GB:.2f} GB exceeds usable memory {usable / GB:.2f} GB "
+                f"({total_memory / GB:.2f} GB * {ecfg.gpu_mem_utilization})")
+        block_bytes = ecfg.block_size * self.model_config.get_kvslot_size(self.dtype)
+        # the two block tables (GPU + CPU manager) are allocated after this point: budget them
+        table_bytes = 2 * ecfg.max_seqs_in_block_table * ecfg.max_blocks_per_seq * 4
+        num_blocks = math.floor((usable - peak_memory - table_bytes) / block_bytes)
+        torch.cuda.empty_cache()
+        return max(num_blocks, 0)
+
+    @torch.inference_mode()
+    def init_kvcache_and_swap(self, num_blocks: int):
+        """Allocate the GPU KV pools, the host swap pools and both block managers.
+        Reference: model.py:134-175."""
+        _require_hip_device()
+        cfg, ecfg = self.model_config, self.engine_config
+        self.num_blocks = num_blocks
+        shape = (num_blocks, cfg.num_layers, cfg.num_kv_heads, ecfg.block_size, cfg.head_dim)
+        # zeros, not empty: stale NaNs in never-written slots would poison 0 * NaN products
+        self.k_cache = torch.zeros(shape, dtype=self.dtype, device=self.device)
+        self.v_cache = torch.zeros(shape, dtype=self.dtype, device=self.device)
+        swap_shape = (ecfg.num_cpu_blocks,) + shape[1:]
+        pin = getattr(ecfg, "pin_swap_memory", True) and ecfg.num_cpu_blocks > 0
+        try:
+            self.k_swap = torch.zeros(swap_shape, dtype=self.dtype, device="cpu", pin_memory=pin)
+            self.v_swap = torch.zeros(swap_shape, dtype=self.dtype, device="cpu", pin_memory=pin)
+        except RuntimeError:    # host cannot pin that much: pageable pools, as the reference has
+            self.k_swap = torch.zeros(swap_shape, dtype=self.dtype, device="cpu")
+            self.v_swap = torch.zeros(swap_shape, dtype=self.dtype, device="cpu")
+        self.gpu_block_manager = BlockManager("GPU", num_blocks, ecfg.max_seqs_in_block_table,
+                                              ecfg.max_blocks_per_seq, ecfg.block_size, self.device)
+        self.cpu_block_manager = BlockManager("CPU", ecfg.num_cpu_blocks,
+                                              ecfg.max_seqs_in_block_table, ecfg.max_blocks_per_seq,
+                                              ecfg.block_size, self.device)
+        self._decode_graphs.clear()
+
+    def _init_to_get_rotary(self):
+        """cos/sin tables [positions, head_dim/2] in the model dtype. Formulas (including the
+        non-HuggingFace frequency split used for dict-valued rope_scaling) follow the reference,
+        model.py:177-225, evaluated in fp32 on the device."""
+        cfg = self.model_config
+        dev, f32 = self.device, torch.float32
+        base, dim = cfg.rope_theta, cfg.head_dim
+        scaling = cfg.rope_scaling
+        if isinstance(scaling, dict):
+            factor = scaling.get("factor", 4.0)
+            low = scaling.get("low_freq_factor", 1.0)
+            high = scaling.get("high_freq_factor", 1.0)
+            orig = scaling.get("original_max_position_embeddings", cfg.max_position_embeddings)
+            t = torch.arange(int(orig * factor) + 128, device=dev, dtype=f32)
+            split = int((dim // 2) * low / (low + high))
+            inv_low = 1.0 / (base ** (torch.arange(0, split * 2, 2, device=dev, dtype=f32) / dim))
+            inv_high = 1.0 / (base ** (torch.arange(split * 2, dim, 2, device=dev, dtype=f32) / dim))
+            freqs = torch.cat([torch.outer(t / low, inv_low), torch.outer(t / high, inv_high)], dim=-1)
+        else:
+            inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2, device=dev, dtype=f32) / dim))
+            t = torch.arange(cfg.max_position_embeddings * scaling + 128, device=dev, dtype=f32) / scaling
+            freqs = torch.outer(t, inv_freq)
+        self._cos_cached = torch.cos(freqs).to(self.dtype).contiguous()
+        self._sin_cached = torch.sin(freqs).to(self.dtype).contiguous()
+
+    # ------------------------------------------------------------------------------------------------
+    def _upload_plan(self, plan: BatchPlan):
+        """Pack the plan's int32 arrays into pinned memory, one async H2D copy, return device views."""
+        layout, total = plan.packed_layout()
+        if self._meta_done is not None:
+            self._meta_done.synchronize()
+        if self._meta_host is None or self._meta_host.numel() < total:
+            ecfg = self.engine_config
+            cap = max(total, 2 * ecfg.max_tokens_in_batch + 8 * ecfg.max_batch_size + 64)
+            self._meta_host = torch.empty(cap, dtype=torch.int32, pin_memory=True)
+            self._meta_host_np = self._meta_host.numpy()
+            self._meta_dev = torch.empty(cap, dtype=torch.int32, device=self.device)
+            self._meta_done = torch.cuda.Event()
+            self._decode_graphs.clear()     # captured graphs point into the old buffer
+        plan.pack_into(self._meta_host_np)
+        self._meta_dev[:total].copy_(self._meta_host[:total], non_blocking=True)
+        self._meta_done.record()
+        return {name: self._meta_dev[off:off + n] for name, off, n in layout}
+
+    def _make_infer_state(self, plan: BatchPlan, dev: dict, ignore_kvcache: bool) -> LlamaInferState:
+        nsb = plan.num_seq_blocks
+        if nsb > 1:
+            need = _hip.scratch_bytes(plan.num_decoding_seqs, self.model_config.num_q_heads,
+                                      self.model_config.head_dim, nsb) // 4
+            if self._scratch is None or self._scratch.numel() < need:
+                self._scratch = torch.empty(need, dtype=torch.float32, device=self.device)
+                self._decode_graphs.clear()
+        return LlamaInferState(
+            batch_size=plan.batch_size, num_tokens=plan.num_tokens,
+            seq_ids=dev["seq_ids"], softmax_scale=self.model_config.head_dim ** -0.5,
+            num_prefill_seqs=plan.num_prefill_seqs, num_prefill_tokens=plan.num_prefill_tokens,
+            prefill_seq_start_locs=dev["prefill_start_locs_with_end"][:plan.num_prefill_seqs],
+            prefill_seq_start_locs_with_end=dev["prefill_start_locs_with_end"],
+            prefill_seq_lens=dev["prefill_seq_lens"], max_prefill_len=plan.max_prefill_len,
+            num_decoding_seqs=plan.num_decoding_seqs, decoding_seq_lens=dev["decoding_seq_lens"],
+            max_decoding_len=plan.max_decoding_len,
+            seq_block_size=plan.seq_block_size, num_seq_blocks=nsb,
+            position_cos=self._cos_cached, position_sin=self._sin_cached,
+            ignore_kvcache=ignore_kvcache,
+            position_indices=dev["position_indices"], last_token_indices=dev["last_token_indices"],
+            paged_attn_scratch=self._scratch if nsb > 1 else None)
+
+    @torch.inference_mode()
+    def _forward(self, input_ids: torch.Tensor, infer_state: LlamaInferState) -> torch.Tensor:
+        """Embedding -> L transformer blocks -> final norm / lm_head / argmax.
+        Reference: model.py:228-249."""
+        x = self.pre_layer.forward(input_ids)
+        residual = torch.zeros_like(x)
+        block_table = None if infer_state.ignore_kvcache else self.gpu_block_manager.block_table
+        for layer in self.transformer_layers:
+            x = layer.forward(x, residual, self.k_cache, self.v_cache, block_table, infer_state)
+        x += residual
+        return self.post_layer.forward(x, infer_state)
+
+    # ---- hipGraph replay of pure-decode steps ------------------------------------------------------------
+    def _graph_bucket(self, plan: BatchPlan):
+        """Captured launch geometry must cover every replay: round the split count up so a graph
+        stays valid while sequences grow (extra workgroups exit on their first instruction)."""
+        sbs = plan.seq_block_size
+        nsb_cap = -(-(plan.max_decoding_len + 1) // sbs)
+        nsb_cap = max(2, 1 << (nsb_cap - 1).bit_length()) if nsb_cap > 1 else 1
+        return sbs, nsb_cap
+
+    def _forward_decode_graph(self, plan: BatchPlan, dev: dict) -> torch.Tensor:
+        sbs, nsb_cap = self._graph_bucket(plan)
+        key = (plan.batch_size, sbs, nsb_cap)
+        entry = self._decode_graphs.get(key)
+        plan.num_seq_blocks = nsb_cap
+        if entry is None:
+            state = self._make_infer_state(plan, dev, False)
+            # one eager run on a side stream first (library handles, workspaces, allocator pools):
+            # nothing may be lazily initialised while the stream is capturing
+            warm = torch.cuda.Stream()
+            warm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(warm):
+                self._forward(dev["input_ids"], state)
+            torch.cuda.current_stream().wait_stream(warm)
+            entry = _DecodeGraph()
+            entry.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(entry.graph):
+                entry.out_tokens = self._forward(dev["input_ids"], state)
+            entry.seq_block_size, entry.num_seq_blocks = sbs, nsb_cap
+            self._decode_graphs[key] = entry
+        entry.graph.replay()
+        return entry.out_tokens
+
+    # ------------------------------------------------------------------------------------------------
+    @torch.inference_mode()
+    def forward(self, input_ids_list: List[List[int]], seq_ids_list: List[int],
+                decoding_seq_lens_list: List[int], ignore_kvcache: bool = False) -> List[int]:
+        """One iteration: prefill sequences first, then decoding sequences (one token each, their
+        lengths in `decoding_seq_lens_list` INCLUDE that token). Returns the greedy next token of
+        every sequence. Reference: model.py:252-359."""
+        if len(input_ids_list) == 0:
+            return []   # the reference's idle engine calls forward([], [], []) in a loop
+        _require_hip_device()
+        plan = plan_batch(input_ids_list, seq_ids_list, decoding_seq_lens_list,
+                          self.model_config.num_kv_heads, self._target_workgroups)
+        if not ignore_kvcache:
+            self.gpu_block_manager.allocate_blocks_for_seqs(seq_ids_list, plan.seq_lengths_list)
+        dev = self._upload_plan(plan)
+        pure_decode = plan.num_prefill_seqs == 0
+        if (pure_decode and not ignore_kvcache and getattr(self.engine_config, "use_hip_graph", False)):
+            tokens = self._forward_decode_graph(plan, dev)
+        else:
+            tokens = self._forward(dev["input_ids"], self._make_infer_state(plan, dev, ignore_kvcache))
+        return tokens.tolist()
+
+    # ---- swapping ----------------------------------------------------------------------------------------
+    def _swap(self, seq_ids_list: List[int], is_swap_in: bool):
+        """Move every block of the given sequences between the GPU pool and the host swap pool.
+        Reference: model.py:361-379. Block ids come from the host mirrors — no device read-back."""
+        if len(seq_ids_list) == 0:
+            return
+        src_mgr = self.cpu_block_manager if is_swap_in else self.gpu_block_manager
+        dst_mgr = self.gpu_block_manager if is_swap_in else self.cpu_block_manager
+        counts = src_mgr.get_num_allocated_blocks_host(seq_ids_list)
+        src_ids = [b for s in seq_ids_list for b in src_mgr.get_block_ids_host(s)]
+        src_mgr.gather_allocated_blocks_and_free(seq_ids_list)
+        dst_mgr.allocate_blocks_for_seqs(seq_ids_list, [c * self.engine_config.block_size for c in counts])
+        dst_ids = [b for s in seq_ids_list for b in dst_mgr.get_block_ids_host(s)]
+        swap_blocks(src_ids, dst_ids, is_swap_in, self.k_cache, self.v_cache, self.k_swap, self.v_swap)
+
+    @torch.inference_mode()
+    def swap_in_seqs(self, seq_ids_list: List[int]):
+        """Bring the sequences' KV blocks back from the host swap pool."""
+        self._swap(seq_ids_list, True)
+
+    @torch.inference_mode()
+    def swap_out_seqs(self, seq_ids_list: List[int]):
+        """Evict the sequences' KV blocks to the host swap pool."""
+        self._swap(seq_ids_list, False)
+
+    @torch.inference_mode()
+    def free_seqs_resources(self, seq_ids_list: List[int]):
+        """Release everything the sequences hold, on both pools. Reference: model.py:402-408."""
+        if len(seq_ids_list) == 0:
+            return
+        self.gpu_block_manager.free_blocks_for_seqs(seq_ids_list)
+        self.cpu_block_manager.free_blocks_for_seqs(seq_ids_list)

@@ -1,0 +1,72 @@
+"""The C-ABI surface: include/swiftllm_hip.h, the ctypes table in swiftllm_amd/_hip.py and the built
+library must agree; the library must load without a GPU; bad arguments come back as error codes."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from swiftllm_amd import _hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "swiftllm_hip.h")
+
+
+def _declared():
+    """name -> number of parameters, parsed from the header's prototypes."""
+    text = open(HEADER, encoding="utf-8").read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(?:int|size_t|const char \*)\s*\*?\s*(swl_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        params = m.group(2).strip()
+        out[m.group(1)] = 0 if params in ("", "void") else len(params.split(","))
+    return out
+
+
+def test_header_declares_the_expected_entry_points():
+    decl = _declared()
+    assert len(decl) >= 19
+    for name in ("swl_paged_attn_decode", "swl_prefill_attn_varlen", "swl_swap_blocks",
+                 "swl_fused_add_rmsnorm", "swl_store_kv_prefill", "swl_block_table_set"):
+        assert name in decl
+
+
+def test_ctypes_table_matches_header():
+    decl = _declared()
+    table = dict(_hip.SIGNATURES)
+    table.update({k: v[0] for k, v in _hip._SPECIAL.items()})
+    assert set(table) == set(decl), set(table) ^ set(decl)
+    for name, argtypes in table.items():
+        assert len(argtypes) == decl[name], name
+
+
+def test_library_loads_and_exports_every_symbol():
+    lib = _hip.load()
+    for name in _declared():
+        assert hasattr(lib, name), f"{name} missing from {_hip.library_path()}"
+    assert lib.swl_abi_version() == _hip.ABI_VERSION
+    assert lib.swl_strerror(0) == b"ok"
+    assert b"bad argument" in lib.swl_strerror(-1)
+
+
+def test_scratch_bytes_formula():
+    # mid_o [Bd, H, nsb, D] fp32 + mid_lse [Bd, H, nsb] fp32 (reference paged_attn.py:170-180)
+    assert _hip.scratch_bytes(32, 32, 128, 5) == 32 * 32 * 5 * 129 * 4
+    assert _hip.scratch_bytes(0, 32, 128, 5) == 0
+
+
+def test_argument_validation_without_a_gpu():
+    """Validation happens before any launch, so it is observable on a CPU-only box."""
+    lib = _hip.load()
+    # empty batches are legal and launch nothing
+    assert lib.swl_rmsnorm(None, None, 1e-5, 0, 4096, _hip.SWL_F16, None) == 0
+    assert lib.swl_silu_mul(None, 0, 14336, _hip.SWL_F16, None) == 0
+    assert lib.swl_swap_blocks(None, None, 0, 1, None, None, None, None, 1 << 20, None) == 0
+    # null pointers / bad shapes
+    assert lib.swl_rmsnorm(None, None, 1e-5, 4, 4096, _hip.SWL_F16, None) == -1
+    assert lib.swl_rmsnorm(None, None, 1e-5, 4, 4095, _hip.SWL_F16, None) == -1
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.addressof(buf) // 16 * 16 + 16
+    assert lib.swl_rmsnorm(p, p, 1e-5, 1, 8, 7, None) == -1     # unknown dtype code
+    with pytest.raises(_hip.HipLibraryError):
+        _hip.call("swl_silu_mul", None, 4, 7, _hip.SWL_F16, None)   # I % 8 != 0

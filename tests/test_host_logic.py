@@ -1,0 +1,250 @@
+"""Host-side logic of the product, checked on CPU against the oracle's restatement of the reference:
+batch planning, split-K heuristic, the host-mirrored block allocator, configs, weight loading, and
+the "no GPU => loud failure" contract."""
+import itertools
+import random
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import eager_ops as ops
+from oracle import synth
+from oracle.ref_model import RefBlockManager
+from swiftllm_amd import _hip
+from swiftllm_amd.engine_config import EngineConfig
+from swiftllm_amd.model_config import LlamaModelConfig
+from swiftllm_amd.worker.batch_plan import plan_batch, select_seq_block_size
+from swiftllm_amd.worker.block_manager import BlockAllocatorHost
+from swiftllm_amd.worker.weight import load_weights
+
+
+def _reference_plan(input_ids_list, decoding_seq_lens_list):
+    """The arithmetic of reference model.py:268-297 and post_layer.py:24-29, with torch on CPU."""
+    num_prefill = len(input_ids_list) - len(decoding_seq_lens_list)
+    flat = list(itertools.chain(*input_ids_list))
+    plens = [len(s) for s in input_ids_list[:num_prefill]]
+    pl = torch.tensor(plens, dtype=torch.int32)
+    starts = torch.cumsum(pl, 0, dtype=torch.int32) - pl
+    dl = torch.tensor(decoding_seq_lens_list, dtype=torch.int32)
+    pos = torch.cat([torch.arange(n, dtype=torch.int32) for n in plens] + [dl - 1]) if flat else dl
+    num_prefill_tokens = len(flat) - len(decoding_seq_lens_list)
+    last = torch.cat((starts + pl - 1, torch.arange(num_prefill_tokens, len(flat), dtype=torch.int32)))
+    return flat, plens, starts, pos, last, num_prefill_tokens
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_plan_batch_matches_reference_arithmetic(seed):
+    rng = random.Random(seed)
+    n_prefill, n_dec = rng.randint(0, 5), rng.randint(0, 6)
+    if n_prefill + n_dec == 0:
+        n_dec = 1
+    prompts = [[rng.randrange(1000) for _ in range(rng.randint(1, 70))] for _ in range(n_prefill)]
+    dec_lens = [rng.randint(1, 3000) for _ in range(n_dec)]
+    ids = prompts + [[rng.randrange(1000)] for _ in range(n_dec)]
+    seq_ids = rng.sample(range(100), n_prefill + n_dec)
+    plan = plan_batch(ids, seq_ids, dec_lens, num_kv_heads=8)
+    flat, plens, starts, pos, last, npt = _reference_plan(ids, dec_lens)
+    assert plan.input_ids.tolist() == flat
+    assert plan.seq_ids.tolist() == seq_ids
+    assert plan.seq_lengths.tolist() == plens + dec_lens
+    assert plan.prefill_seq_lens.tolist() == plens
+    assert plan.prefill_start_locs_with_end[:-1].tolist() == starts.tolist()
+    # the reference ends this array with num_tokens (model.py:340-343); the value every consumer
+    # needs — and ours — is the number of PREFILL tokens (identical on pure-prefill batches)
+    assert plan.prefill_start_locs_with_end[-1] == npt
+    assert plan.position_indices.tolist() == pos.tolist()
+    assert plan.last_token_indices.tolist() == last.tolist()
+    assert plan.num_prefill_tokens == npt and plan.num_tokens == len(flat)
+    assert plan.max_prefill_len == (max(plens) if plens else 0)
+    assert plan.max_decoding_len == (max(dec_lens) if dec_lens else 0)
+    assert plan.seq_block_size == ops.select_seq_block_size(dec_lens, 8)
+    assert plan.num_seq_blocks == -(-plan.max_decoding_len // plan.seq_block_size)
+    # packing round trip
+    layout, total = plan.packed_layout()
+    buf = np.zeros(total, dtype=np.int32)
+    plan.pack_into(buf)
+    for name, off, n in layout:
+        assert off % 4 == 0
+        assert buf[off:off + n].tolist() == getattr(plan, name).tolist()
+
+
+def test_plan_batch_rejects_inconsistent_batches():
+    with pytest.raises(ValueError):
+        plan_batch([[1, 2]], [0, 1], [], 8)
+    with pytest.raises(ValueError):
+        plan_batch([[1, 2]], [0], [5], 8)       # a decoding sequence must bring exactly one token
+
+
+@pytest.mark.parametrize("lens,kvh", [([1024], 8), ([1088] * 32, 8), ([16384] * 4, 32), ([1], 8),
+                                      ([131072], 8), ([100, 5000, 70000], 2), ([], 8)])
+def test_seq_block_size_equals_reference_heuristic(lens, kvh):
+    got = select_seq_block_size(lens, kvh)
+    assert got == ops.select_seq_block_size(lens, kvh)
+    assert got % 16 == 0 and 64 <= got <= 2048
+    # the SURVEY's worked examples (§8 a2)
+    if lens == [1024]:
+        assert got == 64
+    if lens == [1088] * 32:
+        assert got == 256
+    if lens == [16384] * 4:
+        assert got == 2048
+
+
+def _check_same(host: BlockAllocatorHost, ref: RefBlockManager):
+    assert host.num_free_blocks == ref.num_free_blocks
+    assert host.is_free.tolist() == ref.is_block_free.tolist()
+    for s in range(ref.num_seq_allocated_blocks.numel()):
+        n = int(ref.num_seq_allocated_blocks[s])
+        assert host.num_allocated(s) == n
+        assert host.seq_blocks.get(s, [])[:n] == ref.block_table[s, :n].tolist()
+
+
+def test_block_allocator_replays_reference_trace(golden):
+    g = golden("kvcache_blocks.pt")["block_manager_trace"]
+    host = BlockAllocatorHost("GPU", g["num_blocks"], g["max_seqs"], g["mbps"], g["block_size"])
+    for step in g["trace"]:
+        if step["op"] == "alloc":
+            _, picked = host.plan_allocation(step["ids"], step["lens"])
+            assert picked.tolist() == step["ret"].tolist()
+        else:
+            freed = host.release(step["ids"])
+            if step["op"] == "gather":
+                assert freed == step["ret"].tolist()
+        assert host.num_free_blocks == step["num_free"]
+        assert host.is_free.tolist() == step["is_free"].tolist()
+        for s in range(g["max_seqs"]):
+            n = int(step["num_alloc"][s])
+            assert host.seq_blocks.get(s, [])[:n] == step["block_table"][s, :n].tolist()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_block_allocator_random_walk_equals_reference_manager(seed):
+    rng = random.Random(seed)
+    nb, ms, mb, bs = 64, 10, 16, 16
+    host = BlockAllocatorHost("GPU", nb, ms, mb, bs)
+    ref = RefBlockManager("GPU", nb, ms, mb, bs)
+    lens = {}
+    for _ in range(120):
+        op = rng.choice(["alloc", "alloc", "grow", "free", "gather"])
+        if op in ("alloc", "grow"):
+            ids = rng.sample(range(ms), rng.randint(1, 4))
+            targets = [max(lens.get(s, 0), min(mb * bs, lens.get(s, 0) + rng.randint(0, 40))) for s in ids]
+            need = sum(-(-t // bs) - host.num_allocated(s) for s, t in zip(ids, targets))
+            if need > host.num_free_blocks:
+                with pytest.raises(RuntimeError):
+                    host.plan_allocation(ids, targets)
+                continue
+            _, picked = host.plan_allocation(ids, targets)
+            got = ref.allocate_blocks_for_seqs(torch.tensor(ids, dtype=torch.int32),
+                                               torch.tensor(targets, dtype=torch.int32))
+            assert picked.tolist() == got.tolist()      # lowest ids first, batch order
+            lens.update(zip(ids, targets))
+        else:
+            ids = rng.sample(range(ms), rng.randint(1, 3))
+            t = torch.tensor(ids, dtype=torch.int32)
+            freed = host.release(ids)
+            if op == "free":
+                ref.free_blocks_for_seqs(t)
+            else:
+                assert freed == ref.gather_allocated_blocks_and_free(t).tolist()
+            for s in ids:
+                lens.pop(s, None)
+        _check_same(host, ref)
+
+
+def test_block_allocator_errors():
+    host = BlockAllocatorHost("GPU", 4, 4, 2, 16)
+    host.plan_allocation([0], [32])
+    with pytest.raises(AssertionError):
+        host.plan_allocation([0], [16])         # would have to shrink: the reference's logic error
+    with pytest.raises(RuntimeError, match="No enough free blocks"):
+        host.plan_allocation([1, 2], [32, 32])
+    with pytest.raises(RuntimeError):
+        host.plan_allocation([3], [48])         # > max_blocks_per_seq
+    with pytest.raises(RuntimeError):
+        host.plan_allocation([9], [1])          # sequence id outside the table
+
+
+def test_engine_config_is_field_compatible_with_the_reference():
+    # keyword construction exactly as examples/offline.py:22-33 does it
+    ec = EngineConfig(model_path="/x", use_dummy=False, block_size=16, gpu_mem_utilization=0.99,
+                      num_cpu_blocks=0, max_seqs_in_block_table=128, max_blocks_per_seq=2048,
+                      max_batch_size=16, max_tokens_in_batch=2048 * 16)
+    assert ec.dtype == "float16" and ec.fuse_qkv is False
+    import argparse
+    p = argparse.ArgumentParser()
+    EngineConfig.add_cli_args(p)
+    args = p.parse_args(["--model-path", "/m"])
+    ec2 = EngineConfig(**vars(args))            # reference api_server.py:97
+    assert (ec2.block_size, ec2.gpu_mem_utilization, ec2.max_seqs_in_block_table,
+            ec2.max_blocks_per_seq, ec2.max_batch_size, ec2.max_tokens_in_batch) == \
+        (16, 0.97, 4096, 32768, 512, 32768)
+
+
+def test_model_config_fields_and_kvslot_size():
+    mc = LlamaModelConfig(synth.make_config(**synth.LLAMA3_8B))
+    assert (mc.num_layers, mc.num_q_heads, mc.num_kv_heads, mc.head_dim) == (32, 32, 8, 128)
+    assert mc.rope_scaling == 1.0 and mc.rope_theta == 500000.0
+    assert mc.get_kvslot_size() == 131072               # 128 KiB per token
+    assert mc.get_kvslot_size(torch.bfloat16) == 131072
+    with pytest.raises(AssertionError):
+        LlamaModelConfig(dict(synth.make_config(), model_type="gpt2"))
+
+
+@pytest.mark.parametrize("fmt", ["safetensors", "bin"])
+@pytest.mark.parametrize("fuse_qkv", [False, True])
+def test_weight_loading_on_cpu(tmp_path, fmt, fuse_qkv):
+    cfg = synth.make_config()
+    sd = synth.make_state_dict(cfg, seed=3)
+    synth.write_model_dir(str(tmp_path), cfg, sd, fmt=fmt)
+    mc = LlamaModelConfig.load_from_model_path(str(tmp_path))
+    w = load_weights(mc, torch.float16, str(tmp_path), device="cpu", fuse_qkv=fuse_qkv)
+    assert torch.equal(w.wte, sd["model.embed_tokens.weight"])
+    assert torch.equal(w.lm_head, sd["lm_head.weight"])
+    l1 = w.layers[1]
+    up, gate = sd["model.layers.1.mlp.up_proj.weight"], sd["model.layers.1.mlp.gate_proj.weight"]
+    assert torch.equal(l1.up_gate_proj, torch.cat((up, gate)))      # [up ; gate], weight.py:133
+    if fuse_qkv:
+        assert l1.qkv_proj.shape == (128 + 2 * 64, 128) and not hasattr(l1, "q_proj")
+    else:
+        assert torch.equal(l1.k_proj, sd["model.layers.1.self_attn.k_proj.weight"])
+
+
+def test_dummy_weights_and_tied_head(tmp_path):
+    cfg = synth.make_config(rope_scaling=dict(factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                                              original_max_position_embeddings=128))
+    synth.write_model_dir(str(tmp_path), cfg)
+    mc = LlamaModelConfig.load_from_model_path(str(tmp_path))
+    w = load_weights(mc, torch.bfloat16, str(tmp_path), use_dummy=True, device="cpu")
+    assert w.model_version == "llama3.2" and w.lm_head is w.wte      # weight.py:157-163, 199-213
+    assert w.layers[0].down_proj.dtype == torch.bfloat16
+    assert float(w.layers[0].down_proj.abs().max()) <= 1e-3
+
+
+def test_product_fails_loudly_without_a_gpu(tmp_path):
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    cfg = synth.make_config()
+    synth.write_model_dir(str(tmp_path), cfg, synth.make_state_dict(cfg))
+    from swiftllm_amd import LlamaModel
+    ec = EngineConfig(model_path=str(tmp_path), use_dummy=False, block_size=16, gpu_mem_utilization=0.9,
+                      num_cpu_blocks=4, max_seqs_in_block_table=8, max_blocks_per_seq=8,
+                      max_batch_size=4, max_tokens_in_batch=64)
+    model = LlamaModel(ec)                      # reading config.json needs no device
+    with pytest.raises(_hip.HipLibraryError):
+        model.load_weights()
+    from swiftllm_amd.worker.kernels import rmsnorm_inplace
+    with pytest.raises(_hip.HipLibraryError):
+        rmsnorm_inplace(torch.zeros(2, 8, dtype=torch.float16), torch.ones(8, dtype=torch.float16), 1e-5)
+
+
+def test_product_never_imports_the_oracle():
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "swiftllm_amd")
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), encoding="utf-8").read()
+                assert "import oracle" not in text and "from oracle" not in text, os.path.join(dirpath, f)

@@ -1,0 +1,72 @@
+"""The N>1 path on CPU: request sharding arithmetic and the world_size-2 gloo control group that
+bench.py uses for its barrier / max-over-ranks timing (no data-path collective exists)."""
+import os
+import socket
+
+import pytest
+import torch.multiprocessing as mp
+
+from swiftllm_amd import dp
+
+
+@pytest.mark.parametrize("n,world", [(256, 8), (32, 1), (10, 4), (3, 8), (0, 2), (257, 8)])
+def test_shard_bounds_partition_the_requests(n, world):
+    seen = []
+    sizes = []
+    for r in range(world):
+        b, e = dp.shard_bounds(n, r, world)
+        assert 0 <= b <= e <= n
+        seen.extend(range(b, e))
+        sizes.append(e - b)
+    assert seen == list(range(n))               # disjoint, ordered, complete
+    assert max(sizes) - min(sizes) <= 1         # balanced
+    if n == 256 and world == 8:
+        assert sizes == [32] * 8                # BASELINE configs[4]: 256 sequences, 32 per GPU
+
+
+def test_shard_bounds_rejects_bad_rank():
+    with pytest.raises(ValueError):
+        dp.shard_bounds(10, 2, 2)
+
+
+def test_least_loaded_routing():
+    assert dp.least_loaded([5, 3, 3, 9]) == 1
+    assert dp.least_loaded([0]) == 0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    assert dp.init_control_group(timeout_s=60)
+    mine = dp.shard(list(range(7)), rank, world)
+    dp.barrier()
+    units, secs = dp.reduce_job(len(mine) * 10, 1.0 + rank)      # rank 1 is the slow one
+    everything = dp.gather_lists(mine)
+    dp.barrier()
+    q.put((rank, mine, units, secs, everything))
+
+
+def test_two_rank_gloo_control_group():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, m0, u0, s0, e0), (r1, m1, u1, s1, e1) = results
+    assert m0 == [0, 1, 2, 3] and m1 == [4, 5, 6]
+    assert u0 == u1 == 70.0         # whole-job units = sum over ranks
+    assert s0 == s1 == 2.0          # whole-job time = the slowest rank
+    assert e0 == e1 == [[0, 1, 2, 3], [4, 5, 6]]

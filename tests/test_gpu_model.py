@@ -1,0 +1,183 @@
+"""GPU parity tests of the whole data plane: swiftllm_amd.LlamaModel (HIP kernels through the C ABI)
+against (a) the golden run of the reference's own LlamaModel.forward and (b) the oracle model, on
+random-init checkpoints. Bar (BASELINE.json north_star): greedy token ids identical, pre-argmax
+logits within 1e-3 (fp16; bf16 is held to its own rounding: 8 mantissa bits)."""
+import pytest
+import torch
+
+from oracle import synth
+from oracle.ref_model import RefLlamaModel
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine_config(path, **kw):
+    from swiftllm_amd import EngineConfig
+    base = dict(model_path=path, use_dummy=False, block_size=16, gpu_mem_utilization=0.9,
+                num_cpu_blocks=8, max_seqs_in_block_table=16, max_blocks_per_seq=32, max_batch_size=8,
+                max_tokens_in_batch=256)
+    base.update(kw)
+    return EngineConfig(**base)
+
+
+def _make_model(tmp_path, cfg, sd, num_blocks=24, **kw):
+    from swiftllm_amd import LlamaModel
+    synth.write_model_dir(str(tmp_path), cfg, sd)
+    model = LlamaModel(_engine_config(str(tmp_path), **kw))
+    model.load_weights()
+    model.init_kvcache_and_swap(num_blocks)
+    model.post_layer.logits_tap = []
+    return model
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(fuse_qkv=True), dict(fuse_rope_kvstore=False),
+                                  dict(use_hip_graph=True)], ids=["default", "fused_qkv", "unfused_rope", "hipgraph"])
+def test_forward_matches_reference_golden(tmp_path, golden, opts):
+    """The scripted run frozen from the reference (fp16, BASELINE configs[0] model)."""
+    g = golden("e2e_tiny_fp16.pt")
+    cfg, e = g["config"], g["engine"]
+    model = _make_model(tmp_path, cfg, synth.make_state_dict(cfg, seed=g["seed"]), e["num_gpu_blocks"],
+                        num_cpu_blocks=e["num_cpu_blocks"], max_seqs_in_block_table=e["max_seqs_in_block_table"],
+                        max_blocks_per_seq=e["max_blocks_per_seq"], **opts)
+    worst = 0.0
+    for step in g["steps"]:
+        toks = model.forward(step["input_ids"], step["seq_ids"], step["dec_lens"])
+        logits = model.post_layer.logits_tap[-1]
+        worst = max(worst, (logits - step["logits"]).abs().max().item())
+        assert toks == step["tokens"], (step["kind"], toks, step["tokens"])
+    assert worst <= 1e-3, worst
+
+
+def _run_script(model, prompts, decode_steps, seq_ids=None):
+    seq_ids = seq_ids or list(range(len(prompts)))
+    out = [model.forward(prompts, seq_ids, [])]
+    lens = [len(p) for p in prompts]
+    for _ in range(decode_steps):
+        lens = [n + 1 for n in lens]
+        out.append(model.forward([[t] for t in out[-1]], seq_ids, list(lens)))
+    return out
+
+
+@pytest.mark.parametrize("shape", ["TINY", "SMALL64", "SMALL128"])
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_forward_matches_oracle_model(tmp_path, shape, dtype):
+    """head_dim 32 / 64 / 128 (all kernel specialisations), prompts crossing block and tile
+    boundaries, 20 decode steps, both dtypes: identical greedy tokens, close logits."""
+    cfg = synth.make_config(**getattr(synth, shape))
+    tdtype = torch.float16 if dtype == "float16" else torch.bfloat16
+    sd = synth.make_state_dict(cfg, seed=5, dtype=tdtype)
+    from swiftllm_amd import LlamaModelConfig
+    ecfg = dict(max_blocks_per_seq=32, max_tokens_in_batch=1024, dtype=dtype)
+    model = _make_model(tmp_path, cfg, sd, 64, **ecfg)
+    ref = RefLlamaModel(LlamaModelConfig(cfg), _engine_config("", **ecfg), sd, tdtype)
+    ref.init_kvcache_and_swap(64)
+    g = torch.Generator().manual_seed(2)
+    prompts = [torch.randint(0, cfg["vocab_size"], (n,), generator=g).tolist() for n in (1, 16, 17, 130, 65)]
+    got = _run_script(model, prompts, 20)
+    taps = model.post_layer.logits_tap
+    want, worst = [], 0.0
+    want.append(ref.forward(prompts, list(range(5)), []))
+    worst = max(worst, (taps[0] - ref.last_logits).abs().max().item())
+    lens = [len(p) for p in prompts]
+    for i in range(20):
+        lens = [n + 1 for n in lens]
+        # teacher-forced with OUR tokens so one near-tie cannot derail the comparison of later steps
+        want.append(ref.forward([[t] for t in got[i]], list(range(5)), list(lens)))
+        worst = max(worst, (taps[i + 1] - ref.last_logits).abs().max().item())
+    tol = 1e-3 if dtype == "float16" else 8e-3
+    assert worst <= tol, worst
+    assert got == want
+
+
+def test_mixed_batches_free_and_reuse(tmp_path):
+    """Piggybacked prefill+decode batches (two-stream path), freeing and re-using sequence slots and
+    blocks, vs the oracle model step by step."""
+    cfg = synth.make_config(**synth.SMALL64)
+    sd = synth.make_state_dict(cfg, seed=9)
+    from swiftllm_amd import LlamaModelConfig
+    model = _make_model(tmp_path, cfg, sd, 40, max_tokens_in_batch=1024)
+    ref = RefLlamaModel(LlamaModelConfig(cfg), _engine_config("", max_tokens_in_batch=1024), sd, torch.float16)
+    ref.init_kvcache_and_swap(40)
+    g = torch.Generator().manual_seed(4)
+    rp = lambda n: torch.randint(0, cfg["vocab_size"], (n,), generator=g).tolist()   # noqa: E731
+
+    def both(ids, sids, dlens):
+        a = model.forward(ids, sids, dlens)
+        b = ref.forward(ids, sids, dlens)
+        assert (model.post_layer.logits_tap[-1] - ref.last_logits).abs().max().item() <= 1e-3
+        assert a == b
+        return a
+
+    t = both([rp(40), rp(7)], [2, 5], [])
+    lens = {2: 40, 5: 7}
+    for _ in range(3):
+        for s in lens:
+            lens[s] += 1
+        t = both([[t[0]], [t[1]]], [2, 5], [lens[2], lens[5]])
+    # a new prompt rides along with the two decoding sequences
+    for s in lens:
+        lens[s] += 1
+    t = both([rp(33), [t[0]], [t[1]]], [0, 2, 5], [lens[2], lens[5]])
+    lens[0] = 33
+    # sequence 5 finishes: free it on both sides, its blocks must be handed out again (lowest first)
+    model.free_seqs_resources([5])
+    ref.free_seqs_resources([5])
+    assert model.gpu_block_manager.num_free_blocks == ref.gpu_block_manager.num_free_blocks
+    del lens[5]
+    for s in lens:
+        lens[s] += 1
+    t = both([rp(50), [t[0]], [t[1]]], [5, 0, 2], [lens[0], lens[2]])
+    torch.cuda.synchronize()
+    bm, rbm = model.gpu_block_manager, ref.gpu_block_manager
+    assert torch.equal(bm.num_seq_allocated_blocks.cpu(), rbm.num_seq_allocated_blocks)
+    assert torch.equal(bm.is_block_free.cpu(), rbm.is_block_free)
+    for s in (0, 2, 5):
+        n = int(rbm.num_seq_allocated_blocks[s])
+        assert bm.block_table[s, :n].cpu().tolist() == rbm.block_table[s, :n].tolist()
+    assert model.forward([], [], []) == []
+
+
+def test_swap_out_and_in_preserves_generation(tmp_path):
+    """encode -> erase -> decode: swap a sequence out to the host pool, let another sequence overwrite
+    the GPU blocks it held, swap it back in (different block ids) and continue decoding: tokens must
+    equal an undisturbed run."""
+    cfg = synth.make_config(**synth.SMALL64)
+    sd = synth.make_state_dict(cfg, seed=6)
+    g = torch.Generator().manual_seed(8)
+    pa = torch.randint(0, cfg["vocab_size"], (37,), generator=g).tolist()
+    pb = torch.randint(0, cfg["vocab_size"], (60,), generator=g).tolist()
+
+    clean = _make_model(tmp_path / "a", cfg, sd, 16)
+    want = [x[0] for x in _run_script(clean, [pa], 8, [3])]
+
+    model = _make_model(tmp_path / "b", cfg, sd, 16)
+    got = [x[0] for x in _run_script(model, [pa], 3, [3])]
+    model.swap_out_seqs([3])
+    assert model.gpu_block_manager.num_free_blocks == 16
+    assert model.cpu_block_manager.num_free_blocks == 8 - 3
+    _run_script(model, [pb], 2, [1])                    # tramples the freed GPU blocks
+    model.swap_in_seqs([3])
+    assert model.cpu_block_manager.num_free_blocks == 8
+    n = len(pa) + 3
+    last = got[-1]
+    for _ in range(5):
+        n += 1
+        last = model.forward([[last]], [3], [n])[0]
+        got.append(last)
+    assert got == want
+
+
+def test_profile_num_blocks_and_dummy_weights(tmp_path):
+    from swiftllm_amd import LlamaModel
+    cfg = synth.make_config(**synth.SMALL128)
+    synth.write_model_dir(str(tmp_path), cfg)
+    model = LlamaModel(_engine_config(str(tmp_path), use_dummy=True, gpu_mem_utilization=0.5,
+                                      max_batch_size=4, max_tokens_in_batch=512, dtype="bfloat16"))
+    model.load_weights()
+    n = model.profile_num_blocks()
+    free, total = torch.cuda.mem_get_info()
+    block_bytes = 16 * model.model_config.get_kvslot_size(torch.bfloat16)
+    assert 0 < n * block_bytes <= 0.5 * total
+    model.init_kvcache_and_swap(min(n, 64))
+    toks = model.forward([[1, 2, 3, 4, 5]], [0], [])
+    assert len(toks) == 1 and 0 <= toks[0] < cfg["vocab_size"]

@@ -9,7 +9,9 @@ class LlamaPostLayer:
     def __init__(self, model_config, weights):
         self.model_config = model_config
         self.weights = weights
-        self.logits_tap = None  # tests set this to a list to capture the pre-argmax logits
+        # tests set this to a list: every forward appends its pre-argmax logits (the DEVICE tensor — no
+        # host copy here, a forward may be under hipGraph capture)
+        self.logits_tap = None
 
     def forward(self, input_embds: torch.Tensor, infer_state) -> torch.Tensor:
         """[num_tokens, hidden] -> next-token ids int64 [batch_size] (argmax; ties -> lowest id)."""
@@ -24,5 +26,5 @@ class LlamaPostLayer:
         rmsnorm_inplace(last_input, self.weights.final_norm, self.model_config.rms_norm_eps)
         logits = linear(last_input, self.weights.lm_head)   # [batch, vocab]
         if self.logits_tap is not None:
-            self.logits_tap.append(logits.float().cpu())
+            self.logits_tap.append(logits)
         return torch.argmax(logits, dim=1)

@@ -42,7 +42,7 @@ def test_forward_matches_reference_golden(tmp_path, golden, opts):
     worst = 0.0
     for step in g["steps"]:
         toks = model.forward(step["input_ids"], step["seq_ids"], step["dec_lens"])
-        logits = model.post_layer.logits_tap[-1]
+        logits = model.post_layer.logits_tap[-1].float().cpu()
         worst = max(worst, (logits - step["logits"]).abs().max().item())
         assert toks == step["tokens"], (step["kind"], toks, step["tokens"])
     assert worst <= 1e-3, worst
@@ -77,13 +77,13 @@ def test_forward_matches_oracle_model(tmp_path, shape, dtype):
     taps = model.post_layer.logits_tap
     want, worst = [], 0.0
     want.append(ref.forward(prompts, list(range(5)), []))
-    worst = max(worst, (taps[0] - ref.last_logits).abs().max().item())
+    worst = max(worst, (taps[0].float().cpu() - ref.last_logits).abs().max().item())
     lens = [len(p) for p in prompts]
     for i in range(20):
         lens = [n + 1 for n in lens]
         # teacher-forced with OUR tokens so one near-tie cannot derail the comparison of later steps
         want.append(ref.forward([[t] for t in got[i]], list(range(5)), list(lens)))
-        worst = max(worst, (taps[i + 1] - ref.last_logits).abs().max().item())
+        worst = max(worst, (taps[i + 1].float().cpu() - ref.last_logits).abs().max().item())
     tol = 1e-3 if dtype == "float16" else 8e-3
     assert worst <= tol, worst
     assert got == want
@@ -104,7 +104,7 @@ def test_mixed_batches_free_and_reuse(tmp_path):
     def both(ids, sids, dlens):
         a = model.forward(ids, sids, dlens)
         b = ref.forward(ids, sids, dlens)
-        assert (model.post_layer.logits_tap[-1] - ref.last_logits).abs().max().item() <= 1e-3
+        assert (model.post_layer.logits_tap[-1].float().cpu() - ref.last_logits).abs().max().item() <= 1e-3
         assert a == b
         return a
 

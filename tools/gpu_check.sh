@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 echo "== rocminfo" ; rocminfo 2>/dev/null | grep -E "Marketing Name|gfx" | head -4
 nproc; free -g | head -2
 echo "== pytest -m gpu"
-timeout 1500 python -m pytest tests -m gpu -q -x --timeout=600 ${PYTEST_ARGS:-} > gpurun_out/pytest_gpu.log 2>&1
+timeout 1500 python -m pytest tests -m gpu -q --timeout=600 ${PYTEST_ARGS:--x} > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest rc=$?"; tail -40 gpurun_out/pytest_gpu.log
 echo "== smoke"
 timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -5 gpurun_out/smoke.log

@@ -93,11 +93,12 @@ def build_model(args, cfg, num_blocks):
     tensors = [w.wte, w.lm_head, w.final_norm]
     for layer in w.layers:
         tensors += [t for t in vars(layer).values() if isinstance(t, torch.Tensor)]
-    for t in tensors:
-        if t.dim() == 1:
-            t.normal_(0.0, 0.02, generator=g).add_(1.0)
-        else:
-            t.normal_(0.0, 0.02, generator=g)
+    with torch.inference_mode():
+        for t in tensors:
+            if t.dim() == 1:
+                t.normal_(0.0, 0.02, generator=g).add_(1.0)
+            else:
+                t.normal_(0.0, 0.02, generator=g)
     model.init_kvcache_and_swap(num_blocks)
     return model
 

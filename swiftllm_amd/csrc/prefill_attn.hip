@@ -274,7 +274,7 @@ extern "C" int swl_prefill_attn_varlen(void *o, const void *q, const void *k, co
     if (!o || !q || !k || !v || !cu_seqlens) return SWL_ERR_BAD_ARG;
     if (num_q_heads <= 0 || num_kv_heads <= 0 || num_q_heads % num_kv_heads != 0)
         return SWL_ERR_BAD_ARG;
-    if (!(head_dim == 64 || head_dim == 128)) return SWL_ERR_UNSUPPORTED;
+    if (!(head_dim == 32 || head_dim == 64 || head_dim == 128)) return SWL_ERR_UNSUPPORTED;
     if ((q_tok_stride & 7) || (k_tok_stride & 7) || (v_tok_stride & 7) || (o_tok_stride & 3))
         return SWL_ERR_BAD_ARG;
     if (!swl::aligned16(q) || !swl::aligned16(k) || !swl::aligned16(v) ||
@@ -304,8 +304,10 @@ extern "C" int swl_prefill_attn_varlen(void *o, const void *q, const void *k, co
     SWL_DISPATCH_DTYPE(dtype, T, {
         if (head_dim == 128)
             hipLaunchKernelGGL((swl::prefill_attn_kernel<T, 128>), grid, dim3(256), 0, s, p);
-        else
+        else if (head_dim == 64)
             hipLaunchKernelGGL((swl::prefill_attn_kernel<T, 64>), grid, dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((swl::prefill_attn_kernel<T, 32>), grid, dim3(256), 0, s, p);
     });
     return swl::check_launch();
 }

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(T *__restrict__ x, int64_
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float g = to_f(gate[j]);
-            const T act = to_t<T>(g / (1.0f + __expf(-g)));
+            const T act = to_t<T>(g / (1.0f + expf(-g)));
             up[j] = mul_t<T>(up[j], act);
         }
         store8(up_p, up);

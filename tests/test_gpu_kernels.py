@@ -4,7 +4,7 @@ from the reference's Triton kernels, and through size-independent properties at 
 
 Tolerances (written here, per ③ of the task): copies / integer work bit-exact; rotary bit-exact
 (same rounding points, exact fp32 intermediates); rmsnorm / silu <= 1 ulp of the storage dtype
-(fp32 reduction order, exp implementation); attention <= 4e-3 abs vs the reference's fp16-score path
+(fp32 reduction order; silu <= 2 ulp: exp implementation); attention <= 4e-3 abs vs the reference's fp16-score path
 and <= 2e-3 vs the exact-score oracle on N(0,1) data.
 """
 import types
@@ -88,7 +88,9 @@ def test_silu_and_mul(dtype, tokens, inter):
     K().silu_and_mul_inplace(gx)
     gx = gx.cpu()
     assert torch.equal(gx[:, inter:], x[:, inter:])
-    assert ulp_diff_fp16(gx[:, :inter], ex[:, :inter]) <= 1
+    # silu rounded to the storage dtype may differ by 1 ulp (fp32 exp implementations differ in the
+    # last bit); the storage-dtype product can turn that into 2 ulp
+    assert ulp_diff_fp16(gx[:, :inter], ex[:, :inter]) <= 2
 
 
 def test_silu_golden(golden):
@@ -96,7 +98,7 @@ def test_silu_golden(golden):
     x = a["x"].cuda()
     K().silu_and_mul_inplace(x)
     inter = x.shape[1] // 2
-    assert ulp_diff_fp16(x.cpu()[:, :inter], a["out"][:, :inter]) <= 1
+    assert ulp_diff_fp16(x.cpu()[:, :inter], a["out"][:, :inter]) <= 2
 
 
 # ---- rotary -------------------------------------------------------------------------------------------

@@ -83,7 +83,10 @@ __device__ __forceinline__ void attend_block(const vec8_t<T> (&qv)[G],
 #pragma unroll
         for (int i = 0; i < NI; ++i) m_new = fmaxf(m_new, s[i]);
         const float mc = m_new * c;
-        const float alpha = fast_exp2(fmaf(m[g], c, -mc));
+        // difference FIRST: with both maxima at the -1e30 sentinel (a row that has seen no valid
+        // token yet) fma(m, c, -mc) would return the rounding residual of the product (~1e22) and
+        // exp2 of that is inf; (m - m_new) is exactly 0.
+        const float alpha = fast_exp2((m[g] - m_new) * c);
         float p[NI];
         float psum = 0.f;
 #pragma unroll

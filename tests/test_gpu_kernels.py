@@ -280,9 +280,13 @@ def test_paged_attention_split_invariance_and_properties():
     blk = int(bt[seq_ids[0], 0])
     v0 = vc[blk, layer, :, 0, :].repeat_interleave(H // KVH, dim=0)
     assert torch.equal(outs[0][0], v0)
-    # linearity in V: attn(q, K, 2V) == 2 attn(q, K, V) (exact in fp: power-of-two scaling)
+    # linearity in V: attn(q, K, 2V) == 2 attn(q, K, V). Power-of-two scaling is exact in fp32 all the
+    # way to the store; only outputs in fp16's subnormal range (|x| < 6.1e-5, fixed 6e-8 grid) may
+    # round differently
     o2 = _run_paged(q, kc, vc * 2, bt, lens, seq_ids, 256, H, KVH, D, L, layer)
-    assert torch.equal(o2, outs[1] * 2)
+    assert (o2.float() - 2 * outs[1].float()).abs().max().item() <= 1.2e-7
+    normal = outs[1].float().abs() >= 2.0 ** -13
+    assert torch.equal(o2[normal], (outs[1] * 2)[normal])
 
 
 def test_paged_attention_ignores_stale_tail_and_other_layers():

@@ -125,7 +125,7 @@ def kernel_roofline(model, lens, iters):
     from swiftllm_amd.worker.batch_plan import plan_batch
     mc, ecfg = model.model_config, model.engine_config
     B, H, KVH, D, L = len(lens), mc.num_q_heads, mc.num_kv_heads, mc.head_dim, mc.num_layers
-    plan = plan_batch([[0]] * B, list(range(B)), lens, KVH, model._target_workgroups)
+    plan = plan_batch([[0]] * B, list(range(B)), lens, KVH, model._num_slots)
     sbs, nsb = model._graph_bucket(plan) if ecfg.use_hip_graph else (plan.seq_block_size, plan.num_seq_blocks)
     dev = model.device
     q = torch.randn(B, H, D, device=dev, dtype=torch.float32).to(model.dtype)

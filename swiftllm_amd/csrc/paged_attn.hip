@@ -6,8 +6,11 @@
 // + q/o (2*Bd*H*D*e) + partials.
 //
 // Design (MI355X-first, not the reference's one-warp-per-q-head mapping):
-//   * grid (seq-block, kv-head, sequence); a workgroup = 4 waves serves ALL G = H/KVH q-heads of its
-//     kv-head, so a KV tile is fetched once instead of G times (the reference leans on L2 for that);
+//   * grid (seq-block, kv-head, sequence); a workgroup = 4 or 8 waves serves ALL G = H/KVH q-heads of
+//     its kv-head, so a KV tile is fetched once instead of G times (the reference leans on L2 for
+//     that). The host sizes the sequence block so a launch is ~one 8-wave workgroup per CU in whole
+//     rounds (batch_plan.select_seq_block_size); with one sequence block the output is written
+//     directly and phase 2 is not launched at all;
 //   * the 16-token x D tile of one (block, layer, kv-head) is 4 KiB contiguous in the pool; a wave
 //     reads it with fully coalesced 16-byte-per-lane loads (lane -> token = i*TPI + lane/LPT,
 //     8-element chunk = lane%LPT), 1 KiB per instruction, non-temporal (read once);
@@ -107,12 +110,16 @@ __device__ __forceinline__ void attend_block(const vec8_t<T> (&qv)[G],
     }
 }
 
-template <typename T, int D, int G>
-__global__ __launch_bounds__(256) void paged_attn_phase1_kernel(PagedAttnParams p) {
+// NW = waves per workgroup: 4 for short sequence blocks (latency-bound launches that want many
+// small workgroups), 8 for long ones (one workgroup per CU, every wave streams many KV blocks and the
+// per-workgroup prologue/merge is amortised; 8 waves x 16 KiB of K/V in flight per CU).
+template <typename T, int D, int G, int NW>
+__global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnParams p) {
     using Tile = DecodeTile<T, D, G>;
     constexpr int LPT = Tile::LPT, TPI = Tile::TPI, NI = Tile::NI;
-    __shared__ float sm_ml[4][G][2];
-    __shared__ float sm_acc[4][G][D];
+    constexpr int NT = NW * 64;
+    __shared__ float sm_ml[NW][G][2];
+    __shared__ float sm_acc[NW][G][D];
 
     const int split = blockIdx.x;
     const int kvh = blockIdx.y;
@@ -176,13 +183,13 @@ __global__ __launch_bounds__(256) void paged_attn_phase1_kernel(PagedAttnParams 
     if (b < blk_end) {
         load_block(b, Ka, Va);
         while (true) {
-            if (b + 4 < blk_end) load_block(b + 4, Kb, Vb);
+            if (b + NW < blk_end) load_block(b + NW, Kb, Vb);
             attend(b, Ka, Va);
-            b += 4;
+            b += NW;
             if (b >= blk_end) break;
-            if (b + 4 < blk_end) load_block(b + 4, Ka, Va);
+            if (b + NW < blk_end) load_block(b + NW, Ka, Va);
             attend(b, Kb, Vb);
-            b += 4;
+            b += NW;
             if (b >= blk_end) break;
         }
     }
@@ -219,17 +226,17 @@ __global__ __launch_bounds__(256) void paged_attn_phase1_kernel(PagedAttnParams 
     }
     __syncthreads();
 
-    // ---- merge the 4 waves and write the partial (or the final output when there is one split) --
+    // ---- merge the NW waves and write the partial (or the final output when there is one split) -
     const int nsb = p.num_seq_blocks;
-    for (int oidx = threadIdx.x; oidx < G * D; oidx += 256) {
+    for (int oidx = threadIdx.x; oidx < G * D; oidx += NT) {
         const int g = oidx / D;
         const int d = oidx % D;
         float M = sm_ml[0][g][0];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) M = fmaxf(M, sm_ml[w][g][0]);
+        for (int w = 1; w < NW; ++w) M = fmaxf(M, sm_ml[w][g][0]);
         float Lsum = 0.f, A = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < NW; ++w) {
             const float wgt = fast_exp2((sm_ml[w][g][0] - M) * c);
             Lsum = fmaf(sm_ml[w][g][1], wgt, Lsum);
             A = fmaf(sm_acc[w][g][d], wgt, A);
@@ -288,7 +295,12 @@ __global__ __launch_bounds__(64) void paged_attn_phase2_kernel(
 template <typename T, int D, int G>
 static int launch_phase1(const PagedAttnParams &p, int Bd, hipStream_t stream) {
     const dim3 grid(p.num_seq_blocks, p.KVH, Bd);
-    hipLaunchKernelGGL((paged_attn_phase1_kernel<T, D, G>), grid, dim3(256), 0, stream, p);
+    // >= 32 KV blocks per sequence block: 8-wave workgroups (>= 4 blocks per wave); else 4 waves.
+    // (G = 8 needs > 256 registers per lane: it stays on 4-wave workgroups, one wave per SIMD.)
+    if (G <= 4 && p.seq_block_size >= 32 * kBlk)
+        hipLaunchKernelGGL((paged_attn_phase1_kernel<T, D, G, 8>), grid, dim3(512), 0, stream, p);
+    else
+        hipLaunchKernelGGL((paged_attn_phase1_kernel<T, D, G, 4>), grid, dim3(256), 0, stream, p);
     return check_launch();
 }
 

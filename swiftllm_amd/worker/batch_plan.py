@@ -12,23 +12,31 @@ import numpy as np
 
 
 def select_seq_block_size(decoding_seq_lens: Sequence[int], num_kv_heads: int,
-                          target_workgroups: int = 1024, min_size: int = 64,
-                          max_blocks_per_seq: int = 128) -> int:
-    """Split-K width (tokens) of flash-decoding.
+                          num_slots: int = 256, max_splits: int = 128) -> int:
+    """Split-K width (tokens) of flash-decoding, sized for MI355X.
 
-    Same search as the reference (model.py:305-324): start at 2048 and halve while the launch would
-    have fewer than `target_workgroups` useful workgroups, the width stays >= min_size and no
-    sequence is cut into more than `max_blocks_per_seq` pieces. Our phase-1 workgroup serves a whole
-    kv-head group, so useful workgroups = KVH * sum(len)/width — numerically the reference's
-    formula; `target_workgroups` = 4 x the CU count (256 on MI355X: 2 co-resident workgroups per CU,
-    two rounds) replaces its "1024 because ~128 SMs" magic number.
+    The reference halves 2048 until `KVH * sum(len) / width >= 1024` programs exist (model.py:305-324:
+    "1024 because ~128 SMs", one 1-warp program per q-head). Our phase-1 workgroup is 8 waves serving
+    a whole kv-head group, one per CU, so the right launch is ~`num_slots` (= CU count, 256)
+    workgroups in whole rounds, each with as many KV blocks as possible:
+
+        width = KVH * sum(len) / num_slots        (tokens per workgroup for one full round)
+
+    rounded up to 64 tokens. When that width already covers the longest sequence there is a single
+    sequence block per sequence — phase 1 writes the output directly and phase 2 is never launched —
+    and the width is rounded up to 256 so it (and a captured hipGraph) stays valid while the
+    sequences grow. The width is a free internal choice: results are invariant up to fp32
+    reassociation, which tests/test_gpu_kernels.py checks.
     """
-    size = 2048
-    total = sum(decoding_seq_lens)
-    longest = max(decoding_seq_lens) if len(decoding_seq_lens) else 0
-    while (num_kv_heads * (total / size) < target_workgroups and size // 2 >= min_size
-           and longest / (size // 2) <= max_blocks_per_seq):
-        size //= 2
+    if len(decoding_seq_lens) == 0:
+        return 2048
+    total = sum(-(-n // 64) * 64 for n in decoding_seq_lens)
+    longest = max(decoding_seq_lens)
+    size = max(64, -(-(num_kv_heads * total) // (num_slots * 64)) * 64)
+    if size >= longest:
+        size = -(-size // 256) * 256
+    while -(-longest // size) > max_splits:
+        size *= 2
     return size
 
 
@@ -78,7 +86,7 @@ class BatchPlan:
 
 def plan_batch(input_ids_list: Sequence[Sequence[int]], seq_ids_list: Sequence[int],
                decoding_seq_lens_list: Sequence[int], num_kv_heads: int,
-               target_workgroups: int = 1024) -> BatchPlan:
+               num_slots: int = 256) -> BatchPlan:
     """Prefill sequences come first in all three lists (reference model.py:268-270); a decoding
     sequence contributes exactly one token and its length INCLUDES that token."""
     batch_size = len(input_ids_list)
@@ -104,7 +112,7 @@ def plan_batch(input_ids_list: Sequence[Sequence[int]], seq_ids_list: Sequence[i
     pos[num_prefill_tokens:] = dl - 1
     last = np.concatenate((starts_with_end[1:] - 1,
                            np.arange(num_prefill_tokens, num_tokens, dtype=np.int32))).astype(np.int32)
-    sbs = select_seq_block_size(decoding_seq_lens_list, num_kv_heads, target_workgroups)
+    sbs = select_seq_block_size(decoding_seq_lens_list, num_kv_heads, num_slots)
     max_dec = max(decoding_seq_lens_list) if num_decoding else 0
     seq_lengths_list = prefill_lens + list(decoding_seq_lens_list)
     return BatchPlan(

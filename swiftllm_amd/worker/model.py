@@ -81,7 +81,7 @@ class LlamaModel:
         self._meta_host_np = None
         self._meta_dev = None       # its device twin (fixed address: hipGraph replays read it)
         self._meta_done = None
-        self._target_workgroups = 1024
+        self._num_slots = 256        # CUs: one 8-wave paged-attention workgroup each
         self._decode_graphs = {}
         self._scratch = None
 
@@ -94,7 +94,7 @@ class LlamaModel:
                                    self.engine_config.use_dummy, device=self.device,
                                    fuse_qkv=getattr(self.engine_config, "fuse_qkv", False))
         self._init_to_get_rotary()
-        self._target_workgroups = 4 * torch.cuda.get_device_properties(self.device).multi_processor_count
+        self._num_slots = torch.cuda.get_device_properties(self.device).multi_processor_count
         side_stream = torch.cuda.Stream()
         self.pre_layer = LlamaPreLayer(self.model_config, self.weight)
         self.transformer_layers = [
@@ -241,11 +241,15 @@ class LlamaModel:
 
     # ---- hipGraph replay of pure-decode steps ------------------------------------------------------------
     def _graph_bucket(self, plan: BatchPlan):
-        """Captured launch geometry must cover every replay: round the split count up so a graph
-        stays valid while sequences grow (extra workgroups exit on their first instruction)."""
+        """Captured launch geometry must cover every replay: the split count is taken for the longest
+        sequence rounded up to its next 64-token boundary (the granule select_seq_block_size works
+        in) and then to a power of two, so a graph stays valid while sequences grow (surplus
+        workgroups exit on their first instruction). A single split stays a single split."""
         sbs = plan.seq_block_size
-        nsb_cap = -(-(plan.max_decoding_len + 1) // sbs)
-        nsb_cap = max(2, 1 << (nsb_cap - 1).bit_length()) if nsb_cap > 1 else 1
+        horizon = -(-(plan.max_decoding_len + 1) // 64) * 64
+        nsb_cap = -(-horizon // sbs)
+        if nsb_cap > 1:
+            nsb_cap = 1 << (nsb_cap - 1).bit_length()
         return sbs, nsb_cap
 
     def _forward_decode_graph(self, plan: BatchPlan, dev: dict) -> torch.Tensor:
@@ -282,7 +286,7 @@ class LlamaModel:
             return []   # the reference's idle engine calls forward([], [], []) in a loop
         _require_hip_device()
         plan = plan_batch(input_ids_list, seq_ids_list, decoding_seq_lens_list,
-                          self.model_config.num_kv_heads, self._target_workgroups)
+                          self.model_config.num_kv_heads, self._num_slots)
         if not ignore_kvcache:
             self.gpu_block_manager.allocate_blocks_for_seqs(seq_ids_list, plan.seq_lengths_list)
         dev = self._upload_plan(plan)

@@ -250,11 +250,12 @@ def test_paged_attention_golden(golden, name):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sbs", [128, 1024])    # 4-wave and 8-wave workgroups; 1024 = single split
 @pytest.mark.parametrize("H,KVH,D", [(32, 8, 128), (32, 32, 128), (8, 1, 128), (8, 4, 64), (4, 2, 32), (16, 2, 64)])
-def test_paged_attention_vs_oracle(dtype, H, KVH, D):
+def test_paged_attention_vs_oracle(dtype, sbs, H, KVH, D):
     g = gen(H * 131 + D)
     lens = [1, 15, 16, 17, 63, 64, 65, 300, 1000]
-    L, layer, sbs = 2, 1, 128
+    L, layer = 2, 1
     q, kc, vc, bt, seq_ids = _paged_case(g, H, KVH, D, L, lens, dtype, layer)
     mc, ec = NS(num_q_heads=H, num_kv_heads=KVH, head_dim=D, num_layers=L), NS(block_size=16)
     eo = torch.zeros_like(q)

@@ -159,9 +159,19 @@ def kernel_roofline(model, lens, iters):
     part_bytes = (splits * H * (D + 1) * 4) if nsb > 1 else B * H * D * e
     alg_bytes = kv_bytes + B * H * D * e + part_bytes
     gbs = alg_bytes / (us * 1e-6) / 1e9
+    # HBM traffic cannot be read from inside this process: it comes from the committed rocprofv3 PMC
+    # passes on this kernel (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/r01_paged_attn_pmc.*),
+    # scaled by bytes to this launch; null for a kernel specialisation that was not profiled.
+    traffic, src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_paged_attn_pmc.json")
+    if os.path.exists(pmc_path) and (H, KVH, D) == (32, 8, 128) and nsb == 1:
+        with open(pmc_path, encoding="utf-8") as f:
+            pmc = json.load(f)
+        traffic = int(alg_bytes * pmc["traffic_over_algorithmic"])
+        src = "profiles/r01_paged_attn_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, scaled by bytes)"
     return dict(bound="hbm", kernel="paged_attn_phase1_kernel", achieved=round(gbs, 1), peak=HBM_PEAK_GBS,
                 unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), frac_of_measured_copy=round(gbs / HBM_COPY_GBS, 4),
-                traffic=None, bytes_per_launch=int(alg_bytes), us_per_launch=round(us, 2),
+                traffic=traffic, traffic_source=src, bytes_per_launch=int(alg_bytes), us_per_launch=round(us, 2),
                 seq_block_size=sbs, num_seq_blocks=nsb, launches=iters)
 
 

@@ -50,6 +50,7 @@ def parse_args():
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float16"])
     ap.add_argument("--no-hip-graph", action="store_true")
     ap.add_argument("--fuse-qkv", action="store_true")
+    ap.add_argument("--skinny-gemm", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-iters", type=int, default=256)
     return ap.parse_args()
@@ -83,7 +84,8 @@ def build_model(args, cfg, num_blocks):
                       num_cpu_blocks=0, max_seqs_in_block_table=max(64, args.batch),
                       max_blocks_per_seq=max(256, (args.prompt_len + args.steps + args.warmup) // 16 + 8),
                       max_batch_size=args.batch, max_tokens_in_batch=args.batch * args.prompt_len,
-                      dtype=args.dtype, fuse_qkv=args.fuse_qkv, use_hip_graph=not args.no_hip_graph)
+                      dtype=args.dtype, fuse_qkv=args.fuse_qkv, use_hip_graph=not args.no_hip_graph,
+                      use_skinny_gemm=args.skinny_gemm)
     model = LlamaModel(ec)
     model.load_weights()
     # random-init weights of the named architecture: N(0, 0.02^2) matrices, norm weights 1 + N(0, 0.02^2)
@@ -291,7 +293,8 @@ def main():
                                f"context {first_ctx}..{last_ctx} in the timed steps)",
                    "global_batch": B * world, "prompt_len": S, "gen_len": gen_total,
                    "parallelism": f"request-sharded dp{world} (independent replicas, no collective)",
-                   "hip_graph": not args.no_hip_graph, "fuse_qkv": args.fuse_qkv, "kv_blocks": num_blocks},
+                   "hip_graph": not args.no_hip_graph, "fuse_qkv": args.fuse_qkv,
+                   "skinny_gemm": args.skinny_gemm, "kv_blocks": num_blocks},
         "prefill_tok_s": round(prefill_units / prefill_max_s, 1),
         "prefill_ms": round(prefill_max_s * 1e3, 2),
         "step_roofline": {"bound": "hbm", "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

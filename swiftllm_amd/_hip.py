@@ -52,6 +52,7 @@ SIGNATURES = {
     "swl_rotary_store_kv_decode": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32,
                                    _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _P],
     "swl_decode_positions": [_P, _P, _I32, _P],
+    "swl_gemm_skinny": [_P, _P, _P, _I32, _I32, _I32, _I64, _I64, _I32, _I32, _P],
 }
 # Entry points that do not follow the "int rc = f(...)" convention.
 _SPECIAL = {

@@ -23,6 +23,7 @@ SOURCES = [
     "prefill_attn.hip",
     "block_table.hip",
     "swap_blocks.hip",
+    "gemm_skinny.hip",
 ]
 HEADERS = ["swl_common.h", os.path.join(ROOT, "include", "swiftllm_hip.h")]
 LIB = os.path.join(HERE, "libswiftllm_hip.so")

@@ -42,6 +42,9 @@ class EngineConfig:
     use_hip_graph: bool = False
     # Fused rotary + decode KV store (one launch instead of two) on pure-decode batches.
     fuse_rope_kvstore: bool = True
+    # Route decode-sized projections (<= 32 tokens) to the hand-written weight-streaming MFMA GEMM
+    # instead of hipBLASLt. Off by default (identical BLAS calls to the reference = tightest parity).
+    use_skinny_gemm: bool = False
     # Allocate the host swap pool in pinned memory (true async DMA for swap_blocks).
     pin_swap_memory: bool = True
 
@@ -69,3 +72,4 @@ class EngineConfig:
         g.add_argument("--dtype", type=str, default="float16", choices=["float16", "bfloat16"])
         g.add_argument("--fuse-qkv", action="store_true")
         g.add_argument("--use-hip-graph", action="store_true")
+        g.add_argument("--use-skinny-gemm", action="store_true")

@@ -1,13 +1,32 @@
 """Dense projections. Reference: swiftllm/worker/kernels/linear.py:3-12.
 
-`F.linear` dispatches to hipBLASLt/rocBLAS on ROCm exactly as the reference's call dispatches to
-cuBLAS; keeping the same torch op keeps the GEMM numerics identical to the reference run on the
-same box. (A hand-written skinny weight-streaming GEMM for decode is SURVEY.md §8f rank 1.)
+Default: `torch.nn.functional.linear`, which dispatches to hipBLASLt/rocBLAS on ROCm exactly as the
+reference's call dispatches to cuBLAS — same GEMM kernels as the reference run on the same box.
+
+`skinny=True` (EngineConfig.use_skinny_gemm) routes decode-sized calls (M <= 32 tokens) to the
+hand-written weight-streaming MFMA kernel `swl_gemm_skinny` (csrc/gemm_skinny.hip): at that size the
+projection is pure HBM streaming of the weight matrix, 77 % of all bytes a decode step moves
+(SURVEY.md §8f rank 1). Larger M (prefill) stays on the BLAS, which is compute-bound territory.
 """
 import torch
 import torch.nn.functional as F
 
+from swiftllm_amd import _hip
 
-def linear(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-    """a[T, in] @ w[out, in]^T -> [T, out]."""
+_SKINNY_MAX_M = 32
+
+
+def linear(a: torch.Tensor, w: torch.Tensor, skinny: bool = False) -> torch.Tensor:
+    """a[T, in] @ w[out, in]^T -> [T, out] (fp32 accumulation, one rounding)."""
+    if (skinny and a.is_cuda and a.dim() == 2 and 0 < a.shape[0] <= _SKINNY_MAX_M
+            and a.dtype == w.dtype and a.dtype in (torch.float16, torch.bfloat16)
+            and w.is_contiguous() and a.stride(1) == 1
+            and w.shape[0] % 32 == 0 and w.shape[1] % 64 == 0 and a.stride(0) % 8 == 0):
+        m, k = a.shape
+        n = w.shape[0]
+        out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+        _hip.call("swl_gemm_skinny", _hip.ptr(out), _hip.ptr(a), _hip.ptr(w), m, n, k,
+                  a.stride(0) if m > 1 else max(a.stride(0), k), n, 0, _hip.dtype_code(a.dtype),
+                  _hip.stream())
+        return out
     return F.linear(a, w)

@@ -9,6 +9,7 @@ class LlamaPostLayer:
     def __init__(self, model_config, weights):
         self.model_config = model_config
         self.weights = weights
+        self.skinny = False     # set by LlamaModel from EngineConfig.use_skinny_gemm
         # tests set this to a list: every forward appends its pre-argmax logits (the DEVICE tensor — no
         # host copy here, a forward may be under hipGraph capture)
         self.logits_tap = None
@@ -24,7 +25,7 @@ class LlamaPostLayer:
                              device=input_embds.device, dtype=torch.int32)))
         last_input = input_embds.index_select(0, idx)    # fresh [batch, hidden] copy
         rmsnorm_inplace(last_input, self.weights.final_norm, self.model_config.rms_norm_eps)
-        logits = linear(last_input, self.weights.lm_head)   # [batch, vocab]
+        logits = linear(last_input, self.weights.lm_head, self.skinny)   # [batch, vocab]
         if self.logits_tap is not None:
             self.logits_tap.append(logits)
         return torch.argmax(logits, dim=1)

@@ -26,15 +26,17 @@ class LlamaTransformerLayer:
         self.weight = weight
         self.decoding_piggyback_stream = decoding_piggyback_stream
         self.layer_id = layer_id
+        self.skinny = bool(getattr(engine_config, "use_skinny_gemm", False))
 
     def _project_qkv(self, x: torch.Tensor):
         cfg, w = self.model_config, self.weight
         hq, hkv = cfg.num_q_heads * cfg.head_dim, cfg.num_kv_heads * cfg.head_dim
         if w.qkv_proj is not None:
-            qkv = linear(x, w.qkv_proj)     # [T, hq + 2*hkv]; q/k/v are column slices of it
+            qkv = linear(x, w.qkv_proj, self.skinny)     # [T, hq + 2*hkv]; q/k/v are column slices
             q, k, v = qkv[:, :hq], qkv[:, hq:hq + hkv], qkv[:, hq + hkv:]
         else:
-            q, k, v = linear(x, w.q_proj), linear(x, w.k_proj), linear(x, w.v_proj)
+            sk = self.skinny
+            q, k, v = linear(x, w.q_proj, sk), linear(x, w.k_proj, sk), linear(x, w.v_proj, sk)
         t = x.shape[0]
         return (q.view(t, cfg.num_q_heads, cfg.head_dim), k.view(t, cfg.num_kv_heads, cfg.head_dim),
                 v.view(t, cfg.num_kv_heads, cfg.head_dim))
@@ -80,8 +82,8 @@ class LlamaTransformerLayer:
             paged_attention(q, k_cache, v_cache, block_table, cfg, ecfg, st, self.layer_id, o)
         q = k = v = None
 
-        attn_out = linear(input_embds, w.o_proj)
+        attn_out = linear(input_embds, w.o_proj, self.skinny)
         fused_add_rmsnorm_inplace(attn_out, residual_buf, w.ffn_norm, cfg.rms_norm_eps)
-        up_gate = linear(attn_out, w.up_gate_proj)
+        up_gate = linear(attn_out, w.up_gate_proj, self.skinny)
         silu_and_mul_inplace(up_gate)
-        return linear(up_gate[:, :cfg.ffn_inter_dim], w.down_proj)
+        return linear(up_gate[:, :cfg.ffn_inter_dim], w.down_proj, self.skinny)

@@ -103,6 +103,7 @@ class LlamaModel:
             for i in range(self.model_config.num_layers)
         ]
         self.post_layer = LlamaPostLayer(self.model_config, self.weight)
+        self.post_layer.skinny = bool(getattr(self.engine_config, "use_skinny_gemm", False))
 
     @torch.inference_mode()
     def profile_num_blocks(self) -> int:

@@ -450,3 +450,43 @@ def test_swap_blocks_round_trip(pinned):
     torch.cuda.synchronize()
     for s, b in zip(src, back):
         assert torch.equal(d_kc[b].cpu(), kc[s]) and torch.equal(d_vc[b].cpu(), vc[s])
+
+
+# ---- skinny GEMM --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [1, 5, 32])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (6144, 4096), (28672, 4096), (4096, 14336), (128, 128), (256, 64), (512, 1024)])
+def test_gemm_skinny_vs_fp32_reference(dtype, M, N, K):
+    """out = round(x @ W^T) with fp32 accumulation: agreement with an fp32 matmul to one rounding of the
+    storage dtype (summation order differs), for every k-split the kernel offers."""
+    from swiftllm_amd import _hip
+    g = gen(N + K + M)
+    x = torch.randn(M, K, generator=g).to(dtype).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dtype).cuda()
+    ref = x.float() @ w.float().T
+    eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    out = K_linear(x, w)
+    assert out.shape == (M, N) and out.dtype == dtype
+    assert ((out.float() - ref).abs() <= eps * ref.abs() + 1e-3 * eps * (K ** 0.5)).all()
+    for ks in (1, 2, 4, 8):
+        if K % (64 * ks):
+            continue
+        o2 = torch.empty_like(out)
+        _hip.call("swl_gemm_skinny", o2.data_ptr(), x.data_ptr(), w.data_ptr(), M, N, K, K, N, ks,
+                  _hip.dtype_code(dtype), _hip.stream())
+        assert ((o2.float() - ref).abs() <= eps * ref.abs() + 1e-3 * eps * (K ** 0.5)).all(), ks
+    # strided activations (the down projection reads up_gate[:, :I]) and exact agreement with itself
+    wide = torch.randn(M, 2 * K, generator=g).to(dtype).cuda()
+    o3 = K_linear(wide[:, :K], w)
+    o4 = K_linear(wide[:, :K].contiguous(), w)
+    assert torch.equal(o3, o4)
+
+
+def K_linear(x, w):
+    return K().linear(x, w, skinny=True)
+
+
+def test_linear_falls_back_to_blas_for_prefill_sizes():
+    x = torch.randn(33, 256, dtype=torch.float16, device="cuda")
+    w = torch.randn(512, 256, dtype=torch.float16, device="cuda")
+    assert torch.equal(K().linear(x, w, skinny=True), torch.nn.functional.linear(x, w))

@@ -55,25 +55,49 @@ __global__ __launch_bounds__(KS * NTW * 64) void gemm_skinny_kernel(
         const T *wp = w + static_cast<int64_t>(n0 + l32) * K + ks * kc + hf * 32;
         const T *xp = x + static_cast<int64_t>(min(l32, M - 1)) * x_stride + ks * kc + hf * 32;
         vec8_t<T> wv[PD][4], xv[PD][4];
-        auto issue = [&](int slot, int ss) {
+        // Every tile walks its K-chunk from a different starting super-step (wrapping around): rows
+        // of W are a power-of-two pitch apart, so waves marching in lockstep would all sit on the
+        // same DRAM channel phase. The order of the fp32 accumulation depends only on the tile index
+        // (deterministic).
+        const int rot = ((blockIdx.x * NTW + nt) * 5 + ks * 3) % nss;
+        auto issue = [&](int slot, int ss_linear) {
+            int ss = ss_linear + rot;
+            ss -= ss >= nss ? nss : 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                wv[slot][j] = load8_nt(wp + ss * kSS + j * 8);
+                // default cache policy on purpose: a 128-byte line of W is consumed by 8 separate
+                // 16-byte loads (4 per lane of a lane pair); the non-temporal hint made every one of
+                // them a fresh trip (measured 2x slower)
+                wv[slot][j] = load8(wp + ss * kSS + j * 8);
                 xv[slot][j] = load8(xp + ss * kSS + j * 8);
             }
         };
+        auto consume = [&](int slot) {
 #pragma unroll
-        for (int p = 0; p < PD; ++p)
-            if (p < nss) issue(p, p);
-        for (int ss = 0; ss < nss; ss += PD) {
+            for (int j = 0; j < 4; ++j) acc = mfma32x32x16(wv[slot][j], xv[slot][j], acc);
+        };
+        // Software pipeline over groups of PD super-steps. The steady-state body has NO branches:
+        // hipcc then emits exact counted waits (vmcnt((PD-1)*8)) before each slot's MFMAs; with a
+        // guard per slot it falls back to vmcnt(0) at the loop head and the pipeline collapses.
+        const int nfull = nss / PD * PD;
+        int ss = 0;
+        if (nfull > 0) {
 #pragma unroll
-            for (int p = 0; p < PD; ++p) {
-                if (ss + p < nss) {
+            for (int p = 0; p < PD; ++p) issue(p, p);
+            for (; ss + PD < nfull; ss += PD) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc = mfma32x32x16(wv[p][j], xv[p][j], acc);
-                    if (ss + p + PD < nss) issue(p, ss + p + PD);
+                for (int p = 0; p < PD; ++p) {
+                    consume(p);
+                    issue(p, ss + p + PD);
                 }
             }
+#pragma unroll
+            for (int p = 0; p < PD; ++p) consume(p);
+            ss = nfull;
+        }
+        for (; ss < nss; ++ss) { // fewer than PD super-steps left
+            issue(0, ss);
+            consume(0);
         }
     }
 
@@ -131,10 +155,10 @@ static int dispatch_gemm(T *out, const T *x, const T *w, int M, int N, int K, in
     if (ks_override > 0) ks = ks_override;
     if (K % (kSS * ks) != 0) return SWL_ERR_UNSUPPORTED;
     switch (ks) {
-    case 1: return launch_gemm<T, 1, 8, 3>(out, x, w, M, N, K, xs, os, stream);
-    case 2: return launch_gemm<T, 2, 4, 3>(out, x, w, M, N, K, xs, os, stream);
-    case 4: return launch_gemm<T, 4, 2, 3>(out, x, w, M, N, K, xs, os, stream);
-    case 8: return launch_gemm<T, 8, 1, 3>(out, x, w, M, N, K, xs, os, stream);
+    case 1: return launch_gemm<T, 1, 8, 4>(out, x, w, M, N, K, xs, os, stream);
+    case 2: return launch_gemm<T, 2, 4, 4>(out, x, w, M, N, K, xs, os, stream);
+    case 4: return launch_gemm<T, 4, 2, 4>(out, x, w, M, N, K, xs, os, stream);
+    case 8: return launch_gemm<T, 8, 1, 4>(out, x, w, M, N, K, xs, os, stream);
     default: return SWL_ERR_UNSUPPORTED;
     }
 }

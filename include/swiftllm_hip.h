@@ -198,12 +198,15 @@ int swl_rotary_store_kv_decode(void *q, void *k, const void *v, const void *cos_
 /* ---- Skinny GEMM for decode batches -----------------------------------------------------------------
  * reference: kernels/linear.py:3-12 (F.linear), call sites transformer_layer.py:54-56,117,126,128 and
  * post_layer.py:38. out[M, N] = x[M, K] . W[N, K]^T with fp32 accumulation and one rounding, for
- * M <= 32 tokens: a weight-streaming MFMA kernel (every byte of W read once, in-workgroup split-K with a
- * fixed reduction order). N % 32 == 0, K % 64 == 0; x/out rows may be strided (elements).
- * k_splits: 0 = choose (>= 2048 waves per launch when K allows), or 1/2/4/8. Larger M: use the BLAS. */
-int swl_gemm_skinny(void *out, const void *x, const void *w, int32_t M, int32_t N, int32_t K,
-                    int64_t x_row_stride, int64_t out_row_stride, int32_t k_splits, int32_t dtype,
-                    swl_stream_t stream);
+ * M <= 32 tokens: a weight-streaming MFMA kernel (every byte of W read once, in full lines). When N/32
+ * tiles cannot fill the chip, K is split across workgroups into fp32 partial slabs in `workspace` and
+ * reduced in a fixed order by a second kernel. N % 32 == 0, K % 128 == 0; x/out rows may be strided
+ * (elements). k_splits: 0 = choose, or a power of two <= 16. Larger M: use the BLAS.
+ * workspace: >= swl_gemm_skinny_workspace_bytes(M, N, K) bytes (0 = none needed). */
+size_t swl_gemm_skinny_workspace_bytes(int32_t M, int32_t N, int32_t K);
+int swl_gemm_skinny(void *out, const void *x, const void *w, void *workspace, size_t workspace_bytes,
+                    int32_t M, int32_t N, int32_t K, int64_t x_row_stride, int64_t out_row_stride,
+                    int32_t k_splits, int32_t dtype, swl_stream_t stream);
 
 /* Per-step decode metadata derived on the device (so a captured hipGraph can be replayed):
  * pos_idx[i] = seq_lens[i] - 1. */

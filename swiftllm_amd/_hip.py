@@ -52,13 +52,14 @@ SIGNATURES = {
     "swl_rotary_store_kv_decode": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32,
                                    _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _P],
     "swl_decode_positions": [_P, _P, _I32, _P],
-    "swl_gemm_skinny": [_P, _P, _P, _I32, _I32, _I32, _I64, _I64, _I32, _I32, _P],
+    "swl_gemm_skinny": [_P, _P, _P, _P, ctypes.c_size_t, _I32, _I32, _I32, _I64, _I64, _I32, _I32, _P],
 }
 # Entry points that do not follow the "int rc = f(...)" convention.
 _SPECIAL = {
     "swl_abi_version": ([], _I32),
     "swl_strerror": ([_I32], ctypes.c_char_p),
     "swl_paged_attn_scratch_bytes": ([_I32, _I32, _I32, _I32], ctypes.c_size_t),
+    "swl_gemm_skinny_workspace_bytes": ([_I32, _I32, _I32], ctypes.c_size_t),
 }
 
 _lock = threading.Lock()

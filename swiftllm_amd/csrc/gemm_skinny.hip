@@ -5,18 +5,22 @@
 // 126,128 and post_layer.py:38). At M <= 32 the op is pure HBM streaming of W (77 % of all bytes a
 // decode step moves); algorithmic bytes = N*K*e (+ M*K*e + M*N*e).
 //
-// Mapping (not a tiled compute GEMM):
-//   * one wave owns 32 consecutive rows of W (output columns) over one K-chunk and issues
-//     v_mfma_f32_32x32x16 with A = W rows, B = x^T: the 32x32 accumulator is out^T[n][m], so all
-//     M <= 32 tokens ride along with every weight byte exactly once;
-//   * loads are 64 contiguous bytes per lane per super-step (4 x dwordx4, non-temporal): lane
-//     (row = l%32, half = l/32) covers k0 + half*32 .. +32, so a row contributes whole 128-byte lines;
-//     the k-order inside a super-step is permuted identically for W and x (a dot product does not
-//     care), which is what makes the contiguous per-lane run legal for the MFMA operand layout;
-//   * PD super-steps (PD x 4 KiB of W per wave) are in flight while the oldest is consumed;
-//     x comes from L2 with the same addressing (rows >= M are clamped and never stored);
-//   * K is split across the KS waves of a workgroup (so even N = 4096 launches >= 1024 waves) and
-//     reduced through LDS in a fixed order: deterministic, no atomics, one rounding at the store.
+// Structure (a streaming kernel, not a tiled compute GEMM):
+//   * one wave owns 32 consecutive rows of W (= 32 output columns) over one K-chunk and issues
+//     v_mfma_f32_32x32x16 with A = W rows, B = x^T: the accumulator is out^T[n][m], so all M <= 32
+//     tokens ride along with every weight byte exactly once;
+//   * W is fetched in FULL lines: one load instruction = 4 rows x 256 contiguous bytes (16 B per lane),
+//     never "fragment-shaped" (an MFMA fragment is 32 rows a row-pitch apart: 64 separate 16-byte
+//     requests per instruction — measured 3 TB/s and a thrashing L1). The tile [32 rows][128 k] is
+//     transposed into the fragment layout through a wave-private, XOR-swizzled LDS tile
+//     (slot = chunk ^ (row & 15): conflict-free for both the 8-lane write groups and the 16-lane
+//     ds_read_b128 groups); the same for the x tile (from L2). No barriers: a wave only ever reads
+//     LDS it wrote itself;
+//   * the NEXT K-tile (8 KiB of W + 8 KiB of x per wave) is in flight in registers while the current
+//     one is transposed and multiplied (branch-free steady state => counted vmcnt waits);
+//   * N/32 tiles alone do not fill 256 CUs for N = 4096..6144, so K is split across workgroups
+//     (grid.y): each split writes an fp32 partial slab, a second tiny kernel adds the slabs in a fixed
+//     order and rounds once. Deterministic, no atomics.
 #include "swl_common.h"
 
 namespace swl {
@@ -28,158 +32,192 @@ __device__ __forceinline__ float16_t mfma32x32x16(vec8_t<bf16> a, vec8_t<bf16> b
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-constexpr int kSS = 64;          // k elements per super-step
-constexpr int kTileStride = 36;  // floats per m-row of a partial tile in LDS (32 + pad)
+constexpr int kKT = 128;    // k elements per tile (256 bytes per row: two full lines)
+constexpr int kGemmWaves = 4;
 
-// KS = k-splits per workgroup, NTW = 32-row tiles per workgroup, PD = super-steps in flight.
-template <typename T, int KS, int NTW, int PD>
-__global__ __launch_bounds__(KS * NTW * 64) void gemm_skinny_kernel(
-    T *__restrict__ out, const T *__restrict__ x, const T *__restrict__ w, int M, int N, int K,
-    int64_t x_stride, int64_t out_stride) {
-    constexpr int NWAVES = KS * NTW;
-    __shared__ __attribute__((aligned(16))) float part[NWAVES][32 * kTileStride];
+template <typename T, bool PARTIAL>
+// 2 waves per SIMD (<= 256 registers): two 4-wave workgroups per CU = 64 KiB of W in flight per CU
+__global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_skinny_kernel(
+    void *__restrict__ out_, const T *__restrict__ x, const T *__restrict__ w, int M, int N, int K,
+    int kc, int64_t x_stride, int64_t out_stride) {
+    // [wave][0 = W tile, 1 = x tile][32 rows x 128 elements, 16-byte slots XOR-swizzled per row]
+    __shared__ __attribute__((aligned(16))) T lds[kGemmWaves][2][32 * kKT];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ks = wave % KS;
-    const int nt = wave / KS;
-    const int n0 = (blockIdx.x * NTW + nt) * 32;
+    const int n0 = (blockIdx.x * kGemmWaves + wave) * 32;
+    if (n0 >= N) return; // no barriers in this kernel: a whole wave may leave
+    const int ksplit = blockIdx.y;
+    const int k_begin = ksplit * kc;
+    const int nkt = kc / kKT;
+
+    // staging map: load instruction i covers rows 4i..4i+3, lane -> (row 4i + lane/16, chunk lane%16)
+    const int rsub = lane >> 4;
+    const int chunk = lane & 15;
+    const T *wsrc = w + static_cast<int64_t>(n0 + rsub) * K + k_begin + chunk * 8;
+    const T *xsrc = x + k_begin + chunk * 8;
+    int xrow_off[8];     // x is M <= 32 rows: 32-bit offsets are ample
+    int lds_wr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + rsub;
+        xrow_off[i] = min(row, M - 1) * static_cast<int>(x_stride); // rows >= M: clamped, never stored
+        lds_wr[i] = row * kKT + ((chunk ^ (row & 15)) << 3);
+    }
+    // fragment map: lane -> (row/column lane%32, k-half lane/32)
     const int l32 = lane & 31;
     const int hf = lane >> 5;
-    const int kc = K / KS;
-    const int nss = kc / kSS;
-    const bool tile_ok = n0 < N; // N % 32 == 0: a tile is either fully inside or fully outside
+    T *wl = &lds[wave][0][0];
+    T *xl = &lds[wave][1][0];
 
+    vec8_t<T> wa[8], xa[8], wb[8], xb[8];
+    auto issue = [&](vec8_t<T>(&wr)[8], vec8_t<T>(&xr)[8], int kt) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            wr[i] = load8_nt(wsrc + static_cast<int64_t>(4 * i) * K + kt * kKT); // full lines, read once
+            xr[i] = load8(xsrc + xrow_off[i] + kt * kKT);
+        }
+    };
     float16_t acc = float16_t{};
-    if (tile_ok) {
-        const T *wp = w + static_cast<int64_t>(n0 + l32) * K + ks * kc + hf * 32;
-        const T *xp = x + static_cast<int64_t>(min(l32, M - 1)) * x_stride + ks * kc + hf * 32;
-        vec8_t<T> wv[PD][4], xv[PD][4];
-        // Every tile walks its K-chunk from a different starting super-step (wrapping around): rows
-        // of W are a power-of-two pitch apart, so waves marching in lockstep would all sit on the
-        // same DRAM channel phase. The order of the fp32 accumulation depends only on the tile index
-        // (deterministic).
-        const int rot = ((blockIdx.x * NTW + nt) * 5 + ks * 3) % nss;
-        auto issue = [&](int slot, int ss_linear) {
-            int ss = ss_linear + rot;
-            ss -= ss >= nss ? nss : 0;
+    auto process = [&](const vec8_t<T>(&wr)[8], const vec8_t<T>(&xr)[8]) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                // default cache policy on purpose: a 128-byte line of W is consumed by 8 separate
-                // 16-byte loads (4 per lane of a lane pair); the non-temporal hint made every one of
-                // them a fresh trip (measured 2x slower)
-                wv[slot][j] = load8(wp + ss * kSS + j * 8);
-                xv[slot][j] = load8(xp + ss * kSS + j * 8);
-            }
-        };
-        auto consume = [&](int slot) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc = mfma32x32x16(wv[slot][j], xv[slot][j], acc);
-        };
-        // Software pipeline over groups of PD super-steps. The steady-state body has NO branches:
-        // hipcc then emits exact counted waits (vmcnt((PD-1)*8)) before each slot's MFMAs; with a
-        // guard per slot it falls back to vmcnt(0) at the loop head and the pipeline collapses.
-        const int nfull = nss / PD * PD;
-        int ss = 0;
-        if (nfull > 0) {
-#pragma unroll
-            for (int p = 0; p < PD; ++p) issue(p, p);
-            for (; ss + PD < nfull; ss += PD) {
-#pragma unroll
-                for (int p = 0; p < PD; ++p) {
-                    consume(p);
-                    issue(p, ss + p + PD);
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < PD; ++p) consume(p);
-            ss = nfull;
+        for (int i = 0; i < 8; ++i) {
+            *reinterpret_cast<vec8_t<T> *>(wl + lds_wr[i]) = wr[i];
+            *reinterpret_cast<vec8_t<T> *>(xl + lds_wr[i]) = xr[i];
         }
-        for (; ss < nss; ++ss) { // fewer than PD super-steps left
-            issue(0, ss);
-            consume(0);
+#pragma unroll
+        for (int kk = 0; kk < kKT / 16; ++kk) {
+            const int off = l32 * kKT + (((2 * kk + hf) ^ (l32 & 15)) << 3);
+            const vec8_t<T> a = *reinterpret_cast<const vec8_t<T> *>(wl + off);
+            const vec8_t<T> b = *reinterpret_cast<const vec8_t<T> *>(xl + off);
+            acc = mfma32x32x16(a, b, acc);
         }
+    };
+
+    // register double buffer; the steady-state body is branch-free (exact counted waits)
+    issue(wa, xa, 0);
+    int kt = 0;
+    for (; kt + 2 < nkt; kt += 2) {
+        issue(wb, xb, kt + 1);
+        process(wa, xa);
+        issue(wa, xa, kt + 2);
+        process(wb, xb);
+    }
+    if (nkt - kt == 2) {
+        issue(wb, xb, kt + 1);
+        process(wa, xa);
+        process(wb, xb);
+    } else {
+        process(wa, xa);
     }
 
-    // acc[r] = out^T[n = (r&3) + 8*(r>>2) + 4*hf][m = l32]; park it as part[wave][m][n]
+    // acc[r] = out^T[n = n0 + (r&3) + 8*(r>>2) + 4*hf][m = l32]
+    if (l32 < M) {
+        if constexpr (PARTIAL) {
+            float *slab = static_cast<float *>(out_) +
+                          (static_cast<int64_t>(ksplit) * M + l32) * N + n0 + 4 * hf;
 #pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-        float4_t v = {acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]};
-        *reinterpret_cast<float4_t *>(&part[wave][l32 * kTileStride + 8 * r4 + 4 * hf]) = v;
-    }
-    __syncthreads();
-
-    // fixed-order reduction over the KS partials of each tile; 8 outputs (16 bytes) per thread
-    constexpr int ITEMS = NTW * 32 * 4; // (tile, m, n8)
-    for (int it = threadIdx.x; it < ITEMS; it += NWAVES * 64) {
-        const int n8 = it & 3;
-        const int m = (it >> 2) & 31;
-        const int t = it >> 7;
-        const int tn0 = (blockIdx.x * NTW + t) * 32;
-        if (m >= M || tn0 >= N) continue;
-        float s[8];
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4_t v = {acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]};
+                *reinterpret_cast<float4_t *>(slab + 8 * r4) = v;
+            }
+        } else {
+            typedef T vec4 __attribute__((ext_vector_type(4)));
+            T *o = static_cast<T *>(out_) + static_cast<int64_t>(l32) * out_stride + n0 + 4 * hf;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s[e] = 0.f;
+            for (int r4 = 0; r4 < 4; ++r4) {
+                vec4 v;
 #pragma unroll
-        for (int k2 = 0; k2 < KS; ++k2) {
-            const float *src = &part[t * KS + k2][m * kTileStride + n8 * 8];
-            const float4_t a = *reinterpret_cast<const float4_t *>(src);
-            const float4_t b = *reinterpret_cast<const float4_t *>(src + 4);
-            s[0] += a[0]; s[1] += a[1]; s[2] += a[2]; s[3] += a[3];
-            s[4] += b[0]; s[5] += b[1]; s[6] += b[2]; s[7] += b[3];
+                for (int e = 0; e < 4; ++e) v[e] = to_t<T>(acc[4 * r4 + e]);
+                *reinterpret_cast<vec4 *>(o + 8 * r4) = v;
+            }
         }
-        vec8_t<T> ov;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ov[e] = to_t<T>(s[e]);
-        store8(out + static_cast<int64_t>(m) * out_stride + tn0 + n8 * 8, ov);
     }
 }
 
-template <typename T, int KS, int NTW, int PD>
-static int launch_gemm(T *out, const T *x, const T *w, int M, int N, int K, int64_t xs, int64_t os,
-                       hipStream_t stream) {
-    const int tiles = N / 32;
-    const dim3 grid((tiles + NTW - 1) / NTW);
-    hipLaunchKernelGGL((gemm_skinny_kernel<T, KS, NTW, PD>), grid, dim3(KS * NTW * 64), 0, stream, out,
-                       x, w, M, N, K, xs, os);
-    return check_launch();
-}
-
-// Pick the k-split so that a launch has >= ~2048 waves (8 per CU) whenever K allows it.
+// out[m][n] = round(sum over splits, in split order) — 4 outputs per thread.
 template <typename T>
-static int dispatch_gemm(T *out, const T *x, const T *w, int M, int N, int K, int64_t xs, int64_t os,
-                         int ks_override, hipStream_t stream) {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(T *__restrict__ out,
+                                                            const float *__restrict__ slabs, int M,
+                                                            int N, int KS, int64_t out_stride) {
+    const int n4 = N >> 2;
+    const int64_t items = static_cast<int64_t>(M) * n4;
+    for (int64_t it = blockIdx.x * 256ll + threadIdx.x; it < items;
+         it += static_cast<int64_t>(gridDim.x) * 256ll) {
+        const int m = static_cast<int>(it / n4);
+        const int c = static_cast<int>(it - static_cast<int64_t>(m) * n4);
+        float4_t s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < KS; ++k) {
+            const float4_t v = *reinterpret_cast<const float4_t *>(
+                slabs + (static_cast<int64_t>(k) * M + m) * N + 4 * c);
+            s += v;
+        }
+        typedef T vec4 __attribute__((ext_vector_type(4)));
+        vec4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = to_t<T>(s[e]);
+        *reinterpret_cast<vec4 *>(out + static_cast<int64_t>(m) * out_stride + 4 * c) = o;
+    }
+}
+
+// K-splits: enough waves (>= 8 per CU) to keep ~64 KiB of W in flight per CU, but never so many that a
+// split has fewer than two K-tiles; large N needs none.
+static int choose_k_splits(int N, int K) {
     const int tiles = N / 32;
     int ks = 1;
-    while (ks < 8 && tiles * ks < 2048 && K % (kSS * ks * 2) == 0) ks *= 2;
-    if (ks_override > 0) ks = ks_override;
-    if (K % (kSS * ks) != 0) return SWL_ERR_UNSUPPORTED;
-    switch (ks) {
-    case 1: return launch_gemm<T, 1, 8, 4>(out, x, w, M, N, K, xs, os, stream);
-    case 2: return launch_gemm<T, 2, 4, 4>(out, x, w, M, N, K, xs, os, stream);
-    case 4: return launch_gemm<T, 4, 2, 4>(out, x, w, M, N, K, xs, os, stream);
-    case 8: return launch_gemm<T, 8, 1, 4>(out, x, w, M, N, K, xs, os, stream);
-    default: return SWL_ERR_UNSUPPORTED;
+    while (ks < 16 && tiles * ks < 2048 && K % (kKT * ks * 2) == 0 && K / (ks * 2) >= 2 * kKT) ks *= 2;
+    return ks;
+}
+
+template <typename T>
+static int run_gemm(T *out, const T *x, const T *w, float *ws, size_t ws_bytes, int M, int N, int K,
+                    int64_t xs, int64_t os, int ks, hipStream_t stream) {
+    if (ks <= 0) ks = choose_k_splits(N, K);
+    if (K % (kKT * ks) != 0) return SWL_ERR_UNSUPPORTED;
+    const int tiles = N / 32;
+    const dim3 grid((tiles + kGemmWaves - 1) / kGemmWaves, ks);
+    const int kc = K / ks;
+    if (ks == 1) {
+        hipLaunchKernelGGL((gemm_skinny_kernel<T, false>), grid, dim3(kGemmWaves * 64), 0, stream, out, x,
+                           w, M, N, K, kc, xs, os);
+        return check_launch();
     }
+    if (!ws || ws_bytes < static_cast<size_t>(ks) * M * N * sizeof(float)) return SWL_ERR_BAD_ARG;
+    hipLaunchKernelGGL((gemm_skinny_kernel<T, true>), grid, dim3(kGemmWaves * 64), 0, stream, ws, x, w, M,
+                       N, K, kc, xs, static_cast<int64_t>(N));
+    const int64_t items = static_cast<int64_t>(M) * (N / 4);
+    const unsigned rgrid = static_cast<unsigned>((items + 255) / 256);
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(rgrid), dim3(256), 0, stream, out, ws, M, N, ks,
+                       os);
+    return check_launch();
 }
 
 } // namespace swl
 
-extern "C" int swl_gemm_skinny(void *out, const void *x, const void *w, int32_t M, int32_t N,
-                               int32_t K, int64_t x_row_stride, int64_t out_row_stride,
-                               int32_t k_splits, int32_t dtype, swl_stream_t stream) {
+extern "C" size_t swl_gemm_skinny_workspace_bytes(int32_t M, int32_t N, int32_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int ks = swl::choose_k_splits(N, K);
+    return ks > 1 ? static_cast<size_t>(16) * M * N * sizeof(float) : 0; // room for any legal override
+}
+
+extern "C" int swl_gemm_skinny(void *out, const void *x, const void *w, void *workspace,
+                               size_t workspace_bytes, int32_t M, int32_t N, int32_t K,
+                               int64_t x_row_stride, int64_t out_row_stride, int32_t k_splits,
+                               int32_t dtype, swl_stream_t stream) {
     if (M < 0 || N <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
     if (M == 0) return SWL_OK;
     if (!out || !x || !w) return SWL_ERR_BAD_ARG;
-    if (M > 32 || (N & 31) || (K & 63)) return SWL_ERR_UNSUPPORTED;
-    if (x_row_stride < K || out_row_stride < N || (x_row_stride & 7) || (out_row_stride & 7))
+    if (M > 32 || (N & 31) || (K & (swl::kKT - 1))) return SWL_ERR_UNSUPPORTED;
+    if (x_row_stride < K || out_row_stride < N || (x_row_stride & 7) || (out_row_stride & 3))
         return SWL_ERR_BAD_ARG;
-    if (!swl::aligned16(out) || !swl::aligned16(x) || !swl::aligned16(w)) return SWL_ERR_BAD_ARG;
-    if (k_splits != 0 && k_splits != 1 && k_splits != 2 && k_splits != 4 && k_splits != 8)
+    if (!swl::aligned16(x) || !swl::aligned16(w) || (reinterpret_cast<uintptr_t>(out) & 7u) ||
+        (workspace && !swl::aligned16(workspace)))
         return SWL_ERR_BAD_ARG;
+    if (k_splits < 0 || k_splits > 16 || (k_splits & (k_splits - 1))) return SWL_ERR_BAD_ARG;
     SWL_DISPATCH_DTYPE(dtype, T, {
-        return swl::dispatch_gemm<T>(static_cast<T *>(out), static_cast<const T *>(x),
-                                     static_cast<const T *>(w), M, N, K, x_row_stride,
-                                     out_row_stride, k_splits, static_cast<hipStream_t>(stream));
+        return swl::run_gemm<T>(static_cast<T *>(out), static_cast<const T *>(x),
+                                static_cast<const T *>(w), static_cast<float *>(workspace),
+                                workspace_bytes, M, N, K, x_row_stride, out_row_stride, k_splits,
+                                static_cast<hipStream_t>(stream));
     });
 }

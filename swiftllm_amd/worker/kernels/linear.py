@@ -14,6 +14,16 @@ import torch.nn.functional as F
 from swiftllm_amd import _hip
 
 _SKINNY_MAX_M = 32
+_workspaces = {}    # device -> persistent fp32 split-K scratch (fixed address: hipGraph replays use it)
+
+
+def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() * 4 < nbytes:
+        # sized once for the widest split projection a LLaMA has (fused qkv / o / down: N <= 16384)
+        ws = torch.empty(max(nbytes, 16 * _SKINNY_MAX_M * 16384 * 4) // 4, dtype=torch.float32, device=device)
+        _workspaces[device] = ws
+    return ws
 
 
 def linear(a: torch.Tensor, w: torch.Tensor, skinny: bool = False) -> torch.Tensor:
@@ -21,11 +31,14 @@ def linear(a: torch.Tensor, w: torch.Tensor, skinny: bool = False) -> torch.Tens
     if (skinny and a.is_cuda and a.dim() == 2 and 0 < a.shape[0] <= _SKINNY_MAX_M
             and a.dtype == w.dtype and a.dtype in (torch.float16, torch.bfloat16)
             and w.is_contiguous() and a.stride(1) == 1
-            and w.shape[0] % 32 == 0 and w.shape[1] % 64 == 0 and a.stride(0) % 8 == 0):
+            and w.shape[0] % 32 == 0 and w.shape[1] % 128 == 0 and a.stride(0) % 8 == 0):
         m, k = a.shape
         n = w.shape[0]
         out = torch.empty((m, n), dtype=a.dtype, device=a.device)
-        _hip.call("swl_gemm_skinny", _hip.ptr(out), _hip.ptr(a), _hip.ptr(w), m, n, k,
+        need = _hip.load().swl_gemm_skinny_workspace_bytes(m, n, k)
+        ws = _workspace(a.device, need) if need else None
+        _hip.call("swl_gemm_skinny", _hip.ptr(out), _hip.ptr(a), _hip.ptr(w), _hip.ptr(ws),
+                  ws.numel() * 4 if ws is not None else 0, m, n, k,
                   a.stride(0) if m > 1 else max(a.stride(0), k), n, 0, _hip.dtype_code(a.dtype),
                   _hip.stream())
         return out

@@ -455,7 +455,7 @@ def test_swap_blocks_round_trip(pinned):
 # ---- skinny GEMM --------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M", [1, 5, 32])
-@pytest.mark.parametrize("N,K", [(4096, 4096), (6144, 4096), (28672, 4096), (4096, 14336), (128, 128), (256, 64), (512, 1024)])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (6144, 4096), (28672, 4096), (4096, 14336), (128, 128), (256, 256), (512, 1024), (96, 384)])
 def test_gemm_skinny_vs_fp32_reference(dtype, M, N, K):
     """out = round(x @ W^T) with fp32 accumulation: agreement with an fp32 matmul to one rounding of the
     storage dtype (summation order differs), for every k-split the kernel offers."""
@@ -468,12 +468,13 @@ def test_gemm_skinny_vs_fp32_reference(dtype, M, N, K):
     out = K_linear(x, w)
     assert out.shape == (M, N) and out.dtype == dtype
     assert ((out.float() - ref).abs() <= eps * ref.abs() + 1e-3 * eps * (K ** 0.5)).all()
-    for ks in (1, 2, 4, 8):
-        if K % (64 * ks):
+    ws = torch.empty(16 * M * N, dtype=torch.float32, device="cuda")
+    for ks in (1, 2, 4, 8, 16):
+        if K % (128 * ks):
             continue
         o2 = torch.empty_like(out)
-        _hip.call("swl_gemm_skinny", o2.data_ptr(), x.data_ptr(), w.data_ptr(), M, N, K, K, N, ks,
-                  _hip.dtype_code(dtype), _hip.stream())
+        _hip.call("swl_gemm_skinny", o2.data_ptr(), x.data_ptr(), w.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                  M, N, K, K, N, ks, _hip.dtype_code(dtype), _hip.stream())
         assert ((o2.float() - ref).abs() <= eps * ref.abs() + 1e-3 * eps * (K ** 0.5)).all(), ks
     # strided activations (the down projection reads up_gate[:, :I]) and exact agreement with itself
     wide = torch.randn(M, 2 * K, generator=g).to(dtype).cuda()

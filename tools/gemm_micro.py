@@ -27,7 +27,12 @@ def main():
     ap.add_argument("--dtype", default="bfloat16")
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--shapes", default="qkv,o,up_gate,down,lm_head")
+    ap.add_argument("--tunable", action="store_true", help="let PyTorch TunableOp pick the BLAS solution")
     a = ap.parse_args()
+    if a.tunable:
+        import torch.cuda.tunable as tun
+        tun.enable(True); tun.tuning_enable(True); tun.set_max_tuning_duration(200); tun.set_rotating_buffer_size(1024)
+        tun.set_filename('/tmp/tunableop.csv')
     dtype = getattr(torch, a.dtype)
     code = _hip.dtype_code(dtype)
     for name in a.shapes.split(","):
@@ -39,12 +44,13 @@ def main():
         res = {"shape": name, "M": a.m, "N": N, "K": K, "MB": round(N * K * 2 / 1e6, 1)}
         t = bench(lambda i: torch.nn.functional.linear(x, ws[i % copies]), a.iters)
         res["blas_us"] = round(t, 2); res["blas_TBps"] = round(N * K * 2 / t / 1e6, 2)
-        for ks in (0, 1, 2, 4, 8):
-            if ks and K % (64 * ks):
+        wsp = torch.empty(16 * a.m * N, dtype=torch.float32, device="cuda")
+        for ks in (0, 1, 2, 4, 8, 16):
+            if ks and (K % (128 * ks) or (ks > 1 and N > 32768)):
                 continue
             def run(i, ks=ks):
-                _hip.call("swl_gemm_skinny", out.data_ptr(), x.data_ptr(), ws[i % copies].data_ptr(), a.m, N, K,
-                          K, N, ks, code, _hip.stream())
+                _hip.call("swl_gemm_skinny", out.data_ptr(), x.data_ptr(), ws[i % copies].data_ptr(), wsp.data_ptr(),
+                          wsp.numel() * 4, a.m, N, K, K, N, ks, code, _hip.stream())
             t = bench(run, a.iters)
             res[f"swl_ks{ks}_us"] = round(t, 2); res[f"swl_ks{ks}_TBps"] = round(N * K * 2 / t / 1e6, 2)
         print(json.dumps(res), flush=True)

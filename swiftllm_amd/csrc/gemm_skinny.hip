@@ -160,12 +160,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(T *__restrict__ out,
     }
 }
 
-// K-splits: enough waves (>= 8 per CU) to keep ~64 KiB of W in flight per CU, but never so many that a
-// split has fewer than two K-tiles; large N needs none.
+// K-splits: the smallest power of two that launches >= 768 waves (3 per CU; each keeps 8-16 KiB of W
+// in flight), never leaving a split fewer than two K-tiles. Measured on MI355X at M = 32 (bf16,
+// tools/gemm_micro.py): N=6144,K=4096 best at 4 splits (15.6 us), N=4096,K=4096 at 8 (13.2 us),
+// N=4096,K=14336 at 8 (26.4 us), N=28672 and N=128256 unsplit (5.25 / 5.22 TB/s): more splits only add
+// slab traffic and reduce work.
 static int choose_k_splits(int N, int K) {
     const int tiles = N / 32;
     int ks = 1;
-    while (ks < 16 && tiles * ks < 2048 && K % (kKT * ks * 2) == 0 && K / (ks * 2) >= 2 * kKT) ks *= 2;
+    while (ks < 16 && tiles * ks < 768 && K % (kKT * ks * 2) == 0 && K / (ks * 2) >= 2 * kKT) ks *= 2;
     return ks;
 }
 

@@ -31,7 +31,9 @@ def _make_model(tmp_path, cfg, sd, num_blocks=24, **kw):
 
 
 @pytest.mark.parametrize("opts", [dict(), dict(fuse_qkv=True), dict(fuse_rope_kvstore=False),
-                                  dict(use_hip_graph=True)], ids=["default", "fused_qkv", "unfused_rope", "hipgraph"])
+                                  dict(use_hip_graph=True), dict(use_skinny_gemm=True),
+                                  dict(use_skinny_gemm=True, fuse_qkv=True, use_hip_graph=True)],
+                         ids=["default", "fused_qkv", "unfused_rope", "hipgraph", "skinny_gemm", "all_on"])
 def test_forward_matches_reference_golden(tmp_path, golden, opts):
     """The scripted run frozen from the reference (fp16, BASELINE configs[0] model)."""
     g = golden("e2e_tiny_fp16.pt")

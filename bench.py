@@ -49,8 +49,8 @@ def parse_args():
     ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama2-7b", "tiny"])
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float16"])
     ap.add_argument("--no-hip-graph", action="store_true")
-    ap.add_argument("--fuse-qkv", action="store_true")
-    ap.add_argument("--skinny-gemm", action="store_true")
+    ap.add_argument("--no-fuse-qkv", dest="fuse_qkv", action="store_false")
+    ap.add_argument("--no-skinny-gemm", dest="skinny_gemm", action="store_false")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-iters", type=int, default=256)
     return ap.parse_args()

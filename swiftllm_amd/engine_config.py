@@ -35,16 +35,15 @@ class EngineConfig:
     # float16 (model.py:70,147); bfloat16 is the headline precision on MI355X.
     dtype: str = "float16"
     # One [h + 2*KVH*D, h] GEMM instead of three (the reference left this commented out,
-    # weight.py:131). Off by default: identical GEMM shapes to the reference = identical hipBLASLt
-    # kernels = the tightest parity.
-    fuse_qkv: bool = False
+    # weight.py:131). fuse_qkv=False + use_skinny_gemm=False reproduces the reference's exact BLAS calls.
+    fuse_qkv: bool = True
     # Capture pure-decode forwards into hipGraphs (one per batch size) and replay them.
     use_hip_graph: bool = False
     # Fused rotary + decode KV store (one launch instead of two) on pure-decode batches.
     fuse_rope_kvstore: bool = True
     # Route decode-sized projections (<= 32 tokens) to the hand-written weight-streaming MFMA GEMM
-    # instead of hipBLASLt. Off by default (identical BLAS calls to the reference = tightest parity).
-    use_skinny_gemm: bool = False
+    # instead of hipBLASLt (prefill-sized calls stay on the BLAS).
+    use_skinny_gemm: bool = True
     # Allocate the host swap pool in pinned memory (true async DMA for swap_blocks).
     pin_swap_memory: bool = True
 
@@ -70,6 +69,6 @@ class EngineConfig:
         g.add_argument("--max-tokens-in-batch", type=int, default=32768,
                        help="Tokens per forward, at most")
         g.add_argument("--dtype", type=str, default="float16", choices=["float16", "bfloat16"])
-        g.add_argument("--fuse-qkv", action="store_true")
+        g.add_argument("--no-fuse-qkv", dest="fuse_qkv", action="store_false")
         g.add_argument("--use-hip-graph", action="store_true")
-        g.add_argument("--use-skinny-gemm", action="store_true")
+        g.add_argument("--no-skinny-gemm", dest="use_skinny_gemm", action="store_false")

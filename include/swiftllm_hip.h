@@ -208,6 +208,34 @@ int swl_gemm_skinny(void *out, const void *x, const void *w, void *workspace, si
                     int32_t M, int32_t N, int32_t K, int64_t x_row_stride, int64_t out_row_stride,
                     int32_t k_splits, int32_t dtype, swl_stream_t stream);
 
+/* Split-K without the reduce launch: the GEMM stops at its fp32 partial slabs [k_splits][M][N] and a FUSED
+ * CONSUMER adds them (slab order, one rounding — bit-identical to swl_gemm_skinny's own reduce):
+ *   o_proj / down_proj  -> swl_splitk_fused_add_rmsnorm      (reference: rmsnorm.py:39-89)
+ *   fused qkv           -> swl_splitk_rotary_store_kv_decode (reference: rotary_emb.py + kvcache_mgmt.py:50-79)
+ *   anything else       -> swl_splitk_reduce */
+int swl_gemm_skinny_choose_splits(int32_t N, int32_t K); /* 0 = shape unsupported, 1 = no split */
+int swl_gemm_skinny_partial(float *slabs, size_t slabs_bytes, const void *x, const void *w, int32_t M,
+                            int32_t N, int32_t K, int64_t x_row_stride, int32_t k_splits,
+                            int32_t dtype, swl_stream_t stream);
+int swl_splitk_reduce(void *out, const float *slabs, int32_t k_splits, int32_t M, int32_t N,
+                      int64_t out_row_stride, int32_t dtype, swl_stream_t stream);
+/* residual <- round(sum slabs) + residual ; x_out <- rmsnorm(residual) * w   (slabs: [k_splits][T][hidden]) */
+int swl_splitk_fused_add_rmsnorm(void *x_out, void *residual, const void *w, float eps,
+                                 const float *slabs, int32_t k_splits, int64_t num_tokens,
+                                 int32_t hidden, int32_t dtype, swl_stream_t stream);
+/* qkv_slabs: [k_splits][Bd][(H+2*KVH)*D]. Writes rotated q, rotated k and v to the (output) buffers
+ * q_out/k_out/v_out and rotated k, v into the paged pools — swl_rotary_store_kv_decode on reduced inputs. */
+int swl_splitk_rotary_store_kv_decode(void *q_out, void *k_out, void *v_out, const float *qkv_slabs,
+                                      int32_t k_splits, const void *cos_table, const void *sin_table,
+                                      const int32_t *pos_idx, void *k_cache, void *v_cache,
+                                      const int32_t *block_table, const int32_t *seq_ids,
+                                      const int32_t *seq_lens, int32_t num_decoding_seqs,
+                                      int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
+                                      int32_t cur_layer, int32_t num_layers, int32_t block_size,
+                                      int32_t max_blocks_per_seq, int64_t q_tok_stride,
+                                      int64_t k_tok_stride, int64_t v_tok_stride, int32_t dtype,
+                                      swl_stream_t stream);
+
 /* Per-step decode metadata derived on the device (so a captured hipGraph can be replayed):
  * pos_idx[i] = seq_lens[i] - 1. */
 int swl_decode_positions(int32_t *pos_idx, const int32_t *seq_lens, int32_t num_decoding_seqs,

@@ -53,6 +53,11 @@ SIGNATURES = {
                                    _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _P],
     "swl_decode_positions": [_P, _P, _I32, _P],
     "swl_gemm_skinny": [_P, _P, _P, _P, ctypes.c_size_t, _I32, _I32, _I32, _I64, _I64, _I32, _I32, _P],
+    "swl_gemm_skinny_partial": [_P, ctypes.c_size_t, _P, _P, _I32, _I32, _I32, _I64, _I32, _I32, _P],
+    "swl_splitk_reduce": [_P, _P, _I32, _I32, _I32, _I64, _I32, _P],
+    "swl_splitk_fused_add_rmsnorm": [_P, _P, _P, _F32, _P, _I32, _I64, _I32, _I32, _P],
+    "swl_splitk_rotary_store_kv_decode": [_P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32,
+                                          _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _P],
 }
 # Entry points that do not follow the "int rc = f(...)" convention.
 _SPECIAL = {
@@ -60,6 +65,7 @@ _SPECIAL = {
     "swl_strerror": ([_I32], ctypes.c_char_p),
     "swl_paged_attn_scratch_bytes": ([_I32, _I32, _I32, _I32], ctypes.c_size_t),
     "swl_gemm_skinny_workspace_bytes": ([_I32, _I32, _I32], ctypes.c_size_t),
+    "swl_gemm_skinny_choose_splits": ([_I32, _I32], _I32),
 }
 
 _lock = threading.Lock()

@@ -172,9 +172,10 @@ static int choose_k_splits(int N, int K) {
     return ks;
 }
 
+// reduce == false: stop after the partial slabs (a fused consumer sums them: swl_splitk_*)
 template <typename T>
 static int run_gemm(T *out, const T *x, const T *w, float *ws, size_t ws_bytes, int M, int N, int K,
-                    int64_t xs, int64_t os, int ks, hipStream_t stream) {
+                    int64_t xs, int64_t os, int ks, hipStream_t stream, bool reduce = true) {
     if (ks <= 0) ks = choose_k_splits(N, K);
     if (K % (kKT * ks) != 0) return SWL_ERR_UNSUPPORTED;
     const int tiles = N / 32;
@@ -188,6 +189,7 @@ static int run_gemm(T *out, const T *x, const T *w, float *ws, size_t ws_bytes, 
     if (!ws || ws_bytes < static_cast<size_t>(ks) * M * N * sizeof(float)) return SWL_ERR_BAD_ARG;
     hipLaunchKernelGGL((gemm_skinny_kernel<T, true>), grid, dim3(kGemmWaves * 64), 0, stream, ws, x, w, M,
                        N, K, kc, xs, static_cast<int64_t>(N));
+    if (!reduce) return check_launch();
     const int64_t items = static_cast<int64_t>(M) * (N / 4);
     const unsigned rgrid = static_cast<unsigned>((items + 255) / 256);
     hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(rgrid), dim3(256), 0, stream, out, ws, M, N, ks,
@@ -223,4 +225,44 @@ extern "C" int swl_gemm_skinny(void *out, const void *x, const void *w, void *wo
                                 workspace_bytes, M, N, K, x_row_stride, out_row_stride, k_splits,
                                 static_cast<hipStream_t>(stream));
     });
+}
+
+extern "C" int swl_gemm_skinny_choose_splits(int32_t N, int32_t K) {
+    if (N <= 0 || K <= 0 || (N & 31) || (K & (swl::kKT - 1))) return 0;
+    return swl::choose_k_splits(N, K);
+}
+
+/* Partial slabs only: slabs[k_splits][M][N] fp32, k_splits = swl_gemm_skinny_choose_splits(N, K) > 1. */
+extern "C" int swl_gemm_skinny_partial(float *slabs, size_t slabs_bytes, const void *x, const void *w,
+                                       int32_t M, int32_t N, int32_t K, int64_t x_row_stride,
+                                       int32_t k_splits, int32_t dtype, swl_stream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
+    if (M == 0) return SWL_OK;
+    if (!slabs || !x || !w || k_splits < 2 || k_splits > 16 || (k_splits & (k_splits - 1)))
+        return SWL_ERR_BAD_ARG;
+    if (M > 32 || (N & 31) || (K & (swl::kKT - 1))) return SWL_ERR_UNSUPPORTED;
+    if (x_row_stride < K || (x_row_stride & 7) || !swl::aligned16(x) || !swl::aligned16(w) ||
+        !swl::aligned16(slabs))
+        return SWL_ERR_BAD_ARG;
+    SWL_DISPATCH_DTYPE(dtype, T, {
+        return swl::run_gemm<T>(static_cast<T *>(nullptr), static_cast<const T *>(x),
+                                static_cast<const T *>(w), slabs, slabs_bytes, M, N, K, x_row_stride, N,
+                                k_splits, static_cast<hipStream_t>(stream), false);
+    });
+}
+
+/* out[M, N] = round(sum_k slabs[k]) in slab order (what swl_gemm_skinny does internally). */
+extern "C" int swl_splitk_reduce(void *out, const float *slabs, int32_t k_splits, int32_t M, int32_t N,
+                                 int64_t out_row_stride, int32_t dtype, swl_stream_t stream) {
+    if (M < 0 || N <= 0 || (N & 3) || k_splits <= 0) return SWL_ERR_BAD_ARG;
+    if (M == 0) return SWL_OK;
+    if (!out || !slabs || out_row_stride < N || (out_row_stride & 3)) return SWL_ERR_BAD_ARG;
+    const int64_t items = static_cast<int64_t>(M) * (N / 4);
+    const unsigned grid = static_cast<unsigned>((items + 255) / 256);
+    SWL_DISPATCH_DTYPE(dtype, T, {
+        hipLaunchKernelGGL((swl::splitk_reduce_kernel<T>), dim3(grid), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), static_cast<T *>(out), slabs, M, N,
+                           k_splits, out_row_stride);
+    });
+    return swl::check_launch();
 }

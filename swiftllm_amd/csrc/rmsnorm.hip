@@ -30,8 +30,9 @@ __device__ __forceinline__ float block_allreduce_sum(float v, float *lds) {
 // NT = threads per block (multiple of 64), VPT = vectors (of 8 elements) per thread.
 template <typename T, int NT, int VPT, bool FUSED_ADD>
 __global__ __launch_bounds__(NT) void rmsnorm_kernel(T *__restrict__ x, T *__restrict__ residual,
-                                                     const T *__restrict__ w, float eps,
-                                                     int hidden) {
+                                                     const T *__restrict__ w, float eps, int hidden,
+                                                     const float *__restrict__ slabs, int ks,
+                                                     int64_t slab_stride) {
     __shared__ float red[NT / 64];
     const int64_t row = blockIdx.x;
     const int nvec = hidden >> 3;
@@ -44,7 +45,9 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(T *__restrict__ x, T *__res
     for (int i = 0; i < VPT; ++i) {
         const int v = threadIdx.x + i * NT;
         if (v < nvec) {
-            vec8_t<T> xv = load8(xr + v * 8);
+            // x either as stored activations or as the split-K partial slabs of the GEMM that produced it
+            vec8_t<T> xv = slabs ? load8_splitk<T>(slabs, ks, slab_stride, row * hidden + v * 8)
+                                 : load8(xr + v * 8);
             if constexpr (FUSED_ADD) {
                 vec8_t<T> rv = load8(rr + v * 8);
 #pragma unroll
@@ -79,12 +82,13 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(T *__restrict__ x, T *__res
 
 template <typename T, bool FUSED_ADD>
 static int launch_rmsnorm(T *x, T *residual, const T *w, float eps, int64_t num_tokens, int hidden,
-                          hipStream_t stream) {
+                          hipStream_t stream, const float *slabs = nullptr, int ks = 0) {
+    const int64_t slab_stride = num_tokens * hidden;
     const int nvec = hidden / 8;
     const dim3 grid(static_cast<unsigned>(num_tokens));
 #define SWL_RMS_CASE(NT, VPT)                                                                    \
     hipLaunchKernelGGL((rmsnorm_kernel<T, NT, VPT, FUSED_ADD>), grid, dim3(NT), 0, stream, x,    \
-                       residual, w, eps, hidden)
+                       residual, w, eps, hidden, slabs, ks, slab_stride)
     if (nvec <= 64) SWL_RMS_CASE(64, 1);
     else if (nvec <= 128) SWL_RMS_CASE(128, 1);
     else if (nvec <= 256) SWL_RMS_CASE(256, 1);
@@ -124,5 +128,22 @@ extern "C" int swl_fused_add_rmsnorm(void *x, void *residual, const void *w, flo
         return swl::launch_rmsnorm<T, true>(static_cast<T *>(x), static_cast<T *>(residual),
                                             static_cast<const T *>(w), eps, num_tokens, hidden,
                                             static_cast<hipStream_t>(stream));
+    });
+}
+
+extern "C" int swl_splitk_fused_add_rmsnorm(void *x_out, void *residual, const void *w, float eps,
+                                            const float *slabs, int32_t k_splits,
+                                            int64_t num_tokens, int32_t hidden, int32_t dtype,
+                                            swl_stream_t stream) {
+    if (num_tokens < 0 || hidden <= 0 || (hidden & 7) || k_splits <= 0) return SWL_ERR_BAD_ARG;
+    if (num_tokens == 0) return SWL_OK;
+    if (!x_out || !residual || !w || !slabs || !swl::aligned16(x_out) || !swl::aligned16(residual) ||
+        !swl::aligned16(w) || !swl::aligned16(slabs))
+        return SWL_ERR_BAD_ARG;
+    if (num_tokens > 0x7fffffffLL) return SWL_ERR_UNSUPPORTED;
+    SWL_DISPATCH_DTYPE(dtype, T, {
+        return swl::launch_rmsnorm<T, true>(static_cast<T *>(x_out), static_cast<T *>(residual),
+                                            static_cast<const T *>(w), eps, num_tokens, hidden,
+                                            static_cast<hipStream_t>(stream), slabs, k_splits);
     });
 }

@@ -63,8 +63,11 @@ __global__ __launch_bounds__(256) void rotary_store_decode_kernel(
     T *__restrict__ v_cache, const int *__restrict__ block_table, const int *__restrict__ seq_ids,
     const int *__restrict__ seq_lens, int H, int KVH, int D, int cur_layer, int num_layers,
     int block_size, int max_blocks_per_seq, int64_t q_tok_stride, int64_t k_tok_stride,
-    int64_t v_tok_stride) {
+    int64_t v_tok_stride, const float *__restrict__ slabs, int ks, int64_t slab_stride) {
+    // With `slabs` the inputs are the split-K partials of the fused qkv projection, [ks][tokens]
+    // [(H + 2*KVH)*D] fp32: they are summed and rounded here, and q/k/v are pure OUTPUT buffers.
     const int64_t tok = blockIdx.x;
+    const int64_t qkv_row = static_cast<int64_t>(H + 2 * KVH) * D;
     const int seq_id = seq_ids[tok];
     const int pos = seq_lens[tok] - 1;
     const int64_t row = pos_idx ? pos_idx[tok] : pos;
@@ -88,8 +91,15 @@ __global__ __launch_bounds__(256) void rotary_store_decode_kernel(
             const bool is_q = hh < H;
             T *base = is_q ? q + tok * q_tok_stride + static_cast<int64_t>(hh) * D
                            : k + tok * k_tok_stride + static_cast<int64_t>(hh - H) * D;
-            vec8_t<T> x0 = load8(base + c * 8);
-            vec8_t<T> x1 = load8(base + (D >> 1) + c * 8);
+            vec8_t<T> x0, x1;
+            if (slabs) { // q heads then k heads are contiguous in a fused-qkv row: offset hh*D for both
+                const int64_t off = tok * qkv_row + static_cast<int64_t>(hh) * D + c * 8;
+                x0 = load8_splitk<T>(slabs, ks, slab_stride, off);
+                x1 = load8_splitk<T>(slabs, ks, slab_stride, off + (D >> 1));
+            } else {
+                x0 = load8(base + c * 8);
+                x1 = load8(base + (D >> 1) + c * 8);
+            }
             rotate8<T>(x0, x1, cv, sv);
             store8(base + c * 8, x0);
             store8(base + (D >> 1) + c * 8, x1);
@@ -102,7 +112,14 @@ __global__ __launch_bounds__(256) void rotary_store_decode_kernel(
             const int vi = item - rot_items;
             const int c = vi % (D >> 3);
             const int kvh = vi / (D >> 3);
-            const vec8_t<T> vv = load8(v + tok * v_tok_stride + static_cast<int64_t>(kvh) * D + c * 8);
+            vec8_t<T> vv;
+            if (slabs) {
+                vv = load8_splitk<T>(slabs, ks, slab_stride,
+                                     tok * qkv_row + static_cast<int64_t>(H + KVH + kvh) * D + c * 8);
+                store8(const_cast<T *>(v) + tok * v_tok_stride + static_cast<int64_t>(kvh) * D + c * 8, vv);
+            } else {
+                vv = load8(v + tok * v_tok_stride + static_cast<int64_t>(kvh) * D + c * 8);
+            }
             store8(v_cache + pool_base + kvh * head_pitch + c * 8, vv);
         }
     }
@@ -148,13 +165,13 @@ extern "C" int swl_rotary(void *q, void *k, const void *cos_table, const void *s
     return swl::check_launch();
 }
 
-extern "C" int swl_rotary_store_kv_decode(
-    void *q, void *k, const void *v, const void *cos_table, const void *sin_table,
-    const int32_t *pos_idx, void *k_cache, void *v_cache, const int32_t *block_table,
-    const int32_t *seq_ids, const int32_t *seq_lens, int32_t num_decoding_seqs, int32_t num_q_heads,
-    int32_t num_kv_heads, int32_t head_dim, int32_t cur_layer, int32_t num_layers,
-    int32_t block_size, int32_t max_blocks_per_seq, int64_t q_tok_stride, int64_t k_tok_stride,
-    int64_t v_tok_stride, int32_t dtype, swl_stream_t stream) {
+static int rotary_store_decode_impl(
+    void *q, void *k, void *v, const void *cos_table, const void *sin_table, const int32_t *pos_idx,
+    void *k_cache, void *v_cache, const int32_t *block_table, const int32_t *seq_ids,
+    const int32_t *seq_lens, int32_t num_decoding_seqs, int32_t num_q_heads, int32_t num_kv_heads,
+    int32_t head_dim, int32_t cur_layer, int32_t num_layers, int32_t block_size,
+    int32_t max_blocks_per_seq, int64_t q_tok_stride, int64_t k_tok_stride, int64_t v_tok_stride,
+    const float *slabs, int32_t k_splits, int32_t dtype, swl_stream_t stream) {
     if (num_decoding_seqs < 0) return SWL_ERR_BAD_ARG;
     if (num_decoding_seqs == 0) return SWL_OK;
     if (!rotary_args_ok(q, k, cos_table, sin_table, num_q_heads, num_kv_heads, head_dim,
@@ -167,6 +184,9 @@ extern "C" int swl_rotary_store_kv_decode(
     if (block_size <= 0 || num_layers <= 0 || cur_layer < 0 || cur_layer >= num_layers ||
         max_blocks_per_seq <= 0)
         return SWL_ERR_BAD_ARG;
+    if (slabs && (k_splits <= 0 || !swl::aligned16(slabs))) return SWL_ERR_BAD_ARG;
+    const int64_t slab_stride = static_cast<int64_t>(num_decoding_seqs) *
+                                (num_q_heads + 2 * num_kv_heads) * head_dim;
     SWL_DISPATCH_DTYPE(dtype, T, {
         hipLaunchKernelGGL((swl::rotary_store_decode_kernel<T>), dim3(num_decoding_seqs), dim3(256),
                            0, static_cast<hipStream_t>(stream), static_cast<T *>(q),
@@ -175,9 +195,39 @@ extern "C" int swl_rotary_store_kv_decode(
                            pos_idx, static_cast<T *>(k_cache), static_cast<T *>(v_cache),
                            block_table, seq_ids, seq_lens, num_q_heads, num_kv_heads, head_dim,
                            cur_layer, num_layers, block_size, max_blocks_per_seq, q_tok_stride,
-                           k_tok_stride, v_tok_stride);
+                           k_tok_stride, v_tok_stride, slabs, k_splits, slab_stride);
     });
     return swl::check_launch();
+}
+
+extern "C" int swl_rotary_store_kv_decode(
+    void *q, void *k, const void *v, const void *cos_table, const void *sin_table,
+    const int32_t *pos_idx, void *k_cache, void *v_cache, const int32_t *block_table,
+    const int32_t *seq_ids, const int32_t *seq_lens, int32_t num_decoding_seqs, int32_t num_q_heads,
+    int32_t num_kv_heads, int32_t head_dim, int32_t cur_layer, int32_t num_layers,
+    int32_t block_size, int32_t max_blocks_per_seq, int64_t q_tok_stride, int64_t k_tok_stride,
+    int64_t v_tok_stride, int32_t dtype, swl_stream_t stream) {
+    return rotary_store_decode_impl(q, k, const_cast<void *>(v), cos_table, sin_table, pos_idx, k_cache,
+                                    v_cache, block_table, seq_ids, seq_lens, num_decoding_seqs,
+                                    num_q_heads, num_kv_heads, head_dim, cur_layer, num_layers,
+                                    block_size, max_blocks_per_seq, q_tok_stride, k_tok_stride,
+                                    v_tok_stride, nullptr, 0, dtype, stream);
+}
+
+extern "C" int swl_splitk_rotary_store_kv_decode(
+    void *q_out, void *k_out, void *v_out, const float *qkv_slabs, int32_t k_splits,
+    const void *cos_table, const void *sin_table, const int32_t *pos_idx, void *k_cache,
+    void *v_cache, const int32_t *block_table, const int32_t *seq_ids, const int32_t *seq_lens,
+    int32_t num_decoding_seqs, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
+    int32_t cur_layer, int32_t num_layers, int32_t block_size, int32_t max_blocks_per_seq,
+    int64_t q_tok_stride, int64_t k_tok_stride, int64_t v_tok_stride, int32_t dtype,
+    swl_stream_t stream) {
+    if (!qkv_slabs) return SWL_ERR_BAD_ARG;
+    return rotary_store_decode_impl(q_out, k_out, v_out, cos_table, sin_table, pos_idx, k_cache, v_cache,
+                                    block_table, seq_ids, seq_lens, num_decoding_seqs, num_q_heads,
+                                    num_kv_heads, head_dim, cur_layer, num_layers, block_size,
+                                    max_blocks_per_seq, q_tok_stride, k_tok_stride, v_tok_stride,
+                                    qkv_slabs, k_splits, dtype, stream);
 }
 
 extern "C" int swl_decode_positions(int32_t *pos_idx, const int32_t *seq_lens,

@@ -132,6 +132,27 @@ __device__ __forceinline__ float wave_allreduce_max(float v) {
     return v;
 }
 
+// Split-K consumers: 8 consecutive outputs of a skinny-GEMM whose K was split across workgroups into `ks`
+// fp32 partial slabs (slab k at slabs + k*slab_stride); summed in slab order, rounded once to T — exactly
+// what the stand-alone reduce kernel of gemm_skinny.hip produces.
+template <typename T>
+__device__ __forceinline__ vec8_t<T> load8_splitk(const float *slabs, int ks, int64_t slab_stride,
+                                                  int64_t elem_off) {
+    float4_t a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    const float *p = slabs + elem_off;
+    for (int k = 0; k < ks; ++k, p += slab_stride) {
+        a += *reinterpret_cast<const float4_t *>(p);
+        b += *reinterpret_cast<const float4_t *>(p + 4);
+    }
+    vec8_t<T> r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        r[e] = static_cast<T>(a[e]);
+        r[4 + e] = static_cast<T>(b[e]);
+    }
+    return r;
+}
+
 // exp2 on the hardware transcendental unit (v_exp_f32 IS 2^x).
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }

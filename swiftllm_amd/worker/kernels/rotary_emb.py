@@ -51,3 +51,29 @@ def rotary_embedding_and_store_kvcache_decode(q: torch.Tensor, k: torch.Tensor, 
               cur_layer, model_config.num_layers, engine_config.block_size, block_table.shape[1],
               token_stride(q, "q"), token_stride(k, "k"), token_stride(v, "v"),
               _hip.dtype_code(q.dtype), _hip.stream())
+
+
+def rotary_embedding_and_store_kvcache_decode_from_splitk(partials, k_cache: torch.Tensor,
+                                                          v_cache: torch.Tensor, block_table: torch.Tensor,
+                                                          model_config, engine_config, infer_state,
+                                                          cur_layer: int):
+    """rotary_embedding_and_store_kvcache_decode fed by the split-K partial slabs of the fused qkv
+    projection: sums + rounds them, rotates q and k, stores k/v into the paged pools, and returns the
+    (rotated) q, k and v as [Bd, heads, head_dim] views of one fresh [Bd, (H+2*KVH)*D] buffer."""
+    assert infer_state.num_prefill_seqs == 0 and infer_state.position_indices is not None
+    nd = infer_state.num_decoding_seqs
+    h, kvh, d = model_config.num_q_heads, model_config.num_kv_heads, model_config.head_dim
+    m, n = partials.shape
+    assert m == nd and n == (h + 2 * kvh) * d
+    qkv = torch.empty((nd, n), dtype=partials.dtype, device=k_cache.device)
+    q = qkv[:, :h * d].view(nd, h, d)
+    k = qkv[:, h * d:(h + kvh) * d].view(nd, kvh, d)
+    v = qkv[:, (h + kvh) * d:].view(nd, kvh, d)
+    _hip.call("swl_splitk_rotary_store_kv_decode", _hip.ptr(q), _hip.ptr(k), _hip.ptr(v),
+              _hip.ptr(partials.slabs), partials.k_splits, _hip.ptr(infer_state.position_cos),
+              _hip.ptr(infer_state.position_sin), _hip.ptr(infer_state.position_indices),
+              _hip.ptr(k_cache), _hip.ptr(v_cache), _hip.ptr(block_table), _hip.ptr(infer_state.seq_ids),
+              _hip.ptr(infer_state.decoding_seq_lens), nd, h, kvh, d, cur_layer, model_config.num_layers,
+              engine_config.block_size, block_table.shape[1], n, n, n, _hip.dtype_code(partials.dtype),
+              _hip.stream())
+    return q, k, v

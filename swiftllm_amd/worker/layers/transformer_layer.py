@@ -7,12 +7,18 @@ by events), output projection, residual-add + FFN norm, up/gate projection, SiLU
 projection. Differences: prefill attention is our own MFMA kernel (the reference calls the
 third-party vllm_flash_attn), q/k/v may come from one fused GEMM, and a pure-decode batch runs on
 one stream with rotary + KV store fused into a single launch.
+
+Decode fast path (use_skinny_gemm): projections whose K is split across workgroups hand their fp32
+partial slabs (SplitKPartials) straight to the next kernel — fused qkv -> rotary+KV-store,
+o_proj -> the FFN's fused_add_rmsnorm, down_proj -> the NEXT layer's fused_add_rmsnorm — so `forward`
+may return, and accept, a SplitKPartials in place of the activation tensor.
 """
 import torch
 
-from ..kernels.linear import linear
-from ..kernels.rmsnorm import fused_add_rmsnorm_inplace
-from ..kernels.rotary_emb import rotary_embedding_inplace, rotary_embedding_and_store_kvcache_decode
+from ..kernels.linear import SplitKPartials, linear, linear_splitk
+from ..kernels.rmsnorm import fused_add_rmsnorm_inplace, fused_add_rmsnorm_from_splitk
+from ..kernels.rotary_emb import (rotary_embedding_inplace, rotary_embedding_and_store_kvcache_decode,
+                                  rotary_embedding_and_store_kvcache_decode_from_splitk)
 from ..kernels.kvcache_mgmt import store_kvcache
 from ..kernels.prefill_attn import prefill_attention
 from ..kernels.paged_attn import paged_attention
@@ -28,36 +34,56 @@ class LlamaTransformerLayer:
         self.layer_id = layer_id
         self.skinny = bool(getattr(engine_config, "use_skinny_gemm", False))
 
-    def _project_qkv(self, x: torch.Tensor):
-        cfg, w = self.model_config, self.weight
+    def _split_qkv(self, qkv: torch.Tensor):
+        cfg = self.model_config
         hq, hkv = cfg.num_q_heads * cfg.head_dim, cfg.num_kv_heads * cfg.head_dim
-        if w.qkv_proj is not None:
-            qkv = linear(x, w.qkv_proj, self.skinny)     # [T, hq + 2*hkv]; q/k/v are column slices
-            q, k, v = qkv[:, :hq], qkv[:, hq:hq + hkv], qkv[:, hq + hkv:]
-        else:
-            sk = self.skinny
-            q, k, v = linear(x, w.q_proj, sk), linear(x, w.k_proj, sk), linear(x, w.v_proj, sk)
-        t = x.shape[0]
-        return (q.view(t, cfg.num_q_heads, cfg.head_dim), k.view(t, cfg.num_kv_heads, cfg.head_dim),
-                v.view(t, cfg.num_kv_heads, cfg.head_dim))
+        t = qkv.shape[0]
+        return (qkv[:, :hq].view(t, cfg.num_q_heads, cfg.head_dim),
+                qkv[:, hq:hq + hkv].view(t, cfg.num_kv_heads, cfg.head_dim),
+                qkv[:, hq + hkv:].view(t, cfg.num_kv_heads, cfg.head_dim))
 
-    def forward(self, input_embds: torch.Tensor, residual_buf: torch.Tensor, k_cache: torch.Tensor,
-                v_cache: torch.Tensor, block_table: torch.Tensor, infer_state) -> torch.Tensor:
+    def _project_qkv(self, x: torch.Tensor):
+        cfg, w, sk = self.model_config, self.weight, self.skinny
+        if w.qkv_proj is not None:
+            return self._split_qkv(linear(x, w.qkv_proj, sk))   # q/k/v are column slices of one output
+        t = x.shape[0]
+        return (linear(x, w.q_proj, sk).view(t, cfg.num_q_heads, cfg.head_dim),
+                linear(x, w.k_proj, sk).view(t, cfg.num_kv_heads, cfg.head_dim),
+                linear(x, w.v_proj, sk).view(t, cfg.num_kv_heads, cfg.head_dim))
+
+    def forward(self, input_embds, residual_buf: torch.Tensor, k_cache: torch.Tensor,
+                v_cache: torch.Tensor, block_table: torch.Tensor, infer_state):
         cfg, ecfg, w, st = self.model_config, self.engine_config, self.weight, infer_state
 
         # residual_buf <- input_embds + residual_buf ; input_embds <- rmsnorm(residual_buf)
-        fused_add_rmsnorm_inplace(input_embds, residual_buf, w.attn_norm, cfg.rms_norm_eps)
-        q, k, v = self._project_qkv(input_embds)
+        if isinstance(input_embds, SplitKPartials):     # the previous layer's down projection, unreduced
+            input_embds = fused_add_rmsnorm_from_splitk(input_embds, residual_buf, w.attn_norm,
+                                                        cfg.rms_norm_eps)
+        else:
+            fused_add_rmsnorm_inplace(input_embds, residual_buf, w.attn_norm, cfg.rms_norm_eps)
 
         pure_decode = st.num_prefill_seqs == 0 and st.num_decoding_seqs > 0
-        if (pure_decode and not st.ignore_kvcache and st.position_indices is not None
-                and getattr(ecfg, "fuse_rope_kvstore", False)):
-            rotary_embedding_and_store_kvcache_decode(q, k, v, k_cache, v_cache, block_table, cfg,
-                                                      ecfg, st, self.layer_id)
+        fused_rope_store = (pure_decode and not st.ignore_kvcache and st.position_indices is not None
+                            and getattr(ecfg, "fuse_rope_kvstore", False))
+        fast = self.skinny and pure_decode
+        if fast and fused_rope_store and w.qkv_proj is not None:
+            qkv = linear_splitk(input_embds, w.qkv_proj)
+            if isinstance(qkv, SplitKPartials):
+                q, k, v = rotary_embedding_and_store_kvcache_decode_from_splitk(
+                    qkv, k_cache, v_cache, block_table, cfg, ecfg, st, self.layer_id)
+            else:
+                q, k, v = self._split_qkv(qkv)
+                rotary_embedding_and_store_kvcache_decode(q, k, v, k_cache, v_cache, block_table, cfg,
+                                                          ecfg, st, self.layer_id)
         else:
-            rotary_embedding_inplace(q, k, st)
-            if not st.ignore_kvcache:
-                store_kvcache(k, v, k_cache, v_cache, block_table, cfg, ecfg, st, self.layer_id)
+            q, k, v = self._project_qkv(input_embds)
+            if fused_rope_store:
+                rotary_embedding_and_store_kvcache_decode(q, k, v, k_cache, v_cache, block_table, cfg,
+                                                          ecfg, st, self.layer_id)
+            else:
+                rotary_embedding_inplace(q, k, st)
+                if not st.ignore_kvcache:
+                    store_kvcache(k, v, k_cache, v_cache, block_table, cfg, ecfg, st, self.layer_id)
 
         # attention output overwrites the (already consumed) normed activations
         o = input_embds.view(-1, cfg.num_q_heads, cfg.head_dim)
@@ -82,8 +108,16 @@ class LlamaTransformerLayer:
             paged_attention(q, k_cache, v_cache, block_table, cfg, ecfg, st, self.layer_id, o)
         q = k = v = None
 
-        attn_out = linear(input_embds, w.o_proj, self.skinny)
-        fused_add_rmsnorm_inplace(attn_out, residual_buf, w.ffn_norm, cfg.rms_norm_eps)
+        if fast:
+            attn_out = linear_splitk(input_embds, w.o_proj)
+            if isinstance(attn_out, SplitKPartials):
+                attn_out = fused_add_rmsnorm_from_splitk(attn_out, residual_buf, w.ffn_norm, cfg.rms_norm_eps)
+            else:
+                fused_add_rmsnorm_inplace(attn_out, residual_buf, w.ffn_norm, cfg.rms_norm_eps)
+        else:
+            attn_out = linear(input_embds, w.o_proj, self.skinny)
+            fused_add_rmsnorm_inplace(attn_out, residual_buf, w.ffn_norm, cfg.rms_norm_eps)
         up_gate = linear(attn_out, w.up_gate_proj, self.skinny)
         silu_and_mul_inplace(up_gate)
-        return linear(up_gate[:, :cfg.ffn_inter_dim], w.down_proj, self.skinny)
+        act = up_gate[:, :cfg.ffn_inter_dim]
+        return linear_splitk(act, w.down_proj) if fast else linear(act, w.down_proj, self.skinny)

@@ -237,6 +237,8 @@ class LlamaModel:
         block_table = None if infer_state.ignore_kvcache else self.gpu_block_manager.block_table
         for layer in self.transformer_layers:
             x = layer.forward(x, residual, self.k_cache, self.v_cache, block_table, infer_state)
+        if not isinstance(x, torch.Tensor):     # the last down projection left as split-K partials
+            x = x.materialize()
         x += residual
         return self.post_layer.forward(x, infer_state)
 

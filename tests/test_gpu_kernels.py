@@ -491,3 +491,66 @@ def test_linear_falls_back_to_blas_for_prefill_sizes():
     x = torch.randn(33, 256, dtype=torch.float16, device="cuda")
     w = torch.randn(512, 256, dtype=torch.float16, device="cuda")
     assert torch.equal(K().linear(x, w, skinny=True), torch.nn.functional.linear(x, w))
+
+
+# ---- split-K consumers: fused kernels must equal "reduce, then the plain kernel" bit for bit ---------
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_splitk_fused_add_rmsnorm_equals_unfused(dtype):
+    from swiftllm_amd.worker.kernels.linear import linear_splitk, SplitKPartials
+    from swiftllm_amd.worker.kernels.rmsnorm import fused_add_rmsnorm_from_splitk
+    g = gen(77)
+    M, N, Kd = 32, 4096, 4096
+    x = torch.randn(M, Kd, generator=g).to(dtype).cuda()
+    w = (torch.randn(N, Kd, generator=g) * 0.02).to(dtype).cuda()
+    res = torch.randn(M, N, generator=g).to(dtype).cuda()
+    nw = (1 + 0.1 * torch.randn(N, generator=g)).to(dtype).cuda()
+    part = linear_splitk(x, w)
+    assert isinstance(part, SplitKPartials) and part.k_splits > 1
+    y = part.materialize()
+    assert torch.equal(y, K().linear(x, w, skinny=True))         # same bits as the self-reducing call
+    r1 = res.clone()
+    K().fused_add_rmsnorm_inplace(y, r1, nw, 1e-5)
+    r2 = res.clone()
+    y2 = fused_add_rmsnorm_from_splitk(part, r2, nw, 1e-5)
+    assert torch.equal(y2, y) and torch.equal(r2, r1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_splitk_rotary_store_equals_unfused(dtype):
+    from swiftllm_amd.worker.kernels.linear import linear_splitk, SplitKPartials
+    from swiftllm_amd.worker.kernels.rotary_emb import (rotary_embedding_and_store_kvcache_decode,
+                                                        rotary_embedding_and_store_kvcache_decode_from_splitk)
+    g = gen(78)
+    H, KVH, D, L, layer, nd, hid = 32, 8, 128, 2, 1, 7, 4096
+    n = (H + 2 * KVH) * D
+    x = torch.randn(nd, hid, generator=g).to(dtype).cuda()
+    wqkv = (torch.randn(n, hid, generator=g) * 0.02).to(dtype).cuda()
+    lens = [1, 16, 17, 33, 100, 64, 5]
+    seq_ids = [3, 0, 6, 1, 2, 5, 4]
+    need = [-(-v // 16) for v in lens]
+    perm = torch.randperm(sum(need) + 2, generator=g).tolist()
+    bt = torch.zeros(8, 16, dtype=torch.int32)
+    for sid, c in zip(seq_ids, need):
+        for j in range(c):
+            bt[sid, j] = perm.pop()
+    bt = bt.cuda()
+    ang = torch.rand(128, D // 2, generator=g) * 6.28
+    st = NS(num_prefill_seqs=0, num_decoding_seqs=nd, position_cos=torch.cos(ang).to(dtype).cuda(),
+            position_sin=torch.sin(ang).to(dtype).cuda(),
+            position_indices=torch.tensor([v - 1 for v in lens], dtype=torch.int32, device="cuda"),
+            seq_ids=torch.tensor(seq_ids, dtype=torch.int32, device="cuda"),
+            decoding_seq_lens=torch.tensor(lens, dtype=torch.int32, device="cuda"))
+    mc, ec = NS(num_q_heads=H, num_kv_heads=KVH, head_dim=D, num_layers=L), NS(block_size=16)
+    shape = (sum(need) + 2, L, KVH, 16, D)
+    part = linear_splitk(x, wqkv)
+    assert isinstance(part, SplitKPartials)
+    qkv = part.materialize()
+    q1 = qkv[:, :H * D].view(nd, H, D)
+    k1 = qkv[:, H * D:(H + KVH) * D].view(nd, KVH, D)
+    v1 = qkv[:, (H + KVH) * D:].view(nd, KVH, D)
+    kc1, vc1 = torch.zeros(shape, dtype=dtype, device="cuda"), torch.zeros(shape, dtype=dtype, device="cuda")
+    rotary_embedding_and_store_kvcache_decode(q1, k1, v1, kc1, vc1, bt, mc, ec, st, layer)
+    kc2, vc2 = torch.zeros_like(kc1), torch.zeros_like(vc1)
+    q2, k2, v2 = rotary_embedding_and_store_kvcache_decode_from_splitk(part, kc2, vc2, bt, mc, ec, st, layer)
+    assert torch.equal(q2, q1) and torch.equal(k2, k1) and torch.equal(v2, v1)
+    assert torch.equal(kc2, kc1) and torch.equal(vc2, vc1)

@@ -51,6 +51,7 @@ def parse_args():
     ap.add_argument("--no-hip-graph", action="store_true")
     ap.add_argument("--no-fuse-qkv", dest="fuse_qkv", action="store_false")
     ap.add_argument("--no-skinny-gemm", dest="skinny_gemm", action="store_false")
+    ap.add_argument("--no-splitk-fusion", dest="splitk_fusion", action="store_false")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-iters", type=int, default=256)
     return ap.parse_args()
@@ -85,7 +86,7 @@ def build_model(args, cfg, num_blocks):
                       max_blocks_per_seq=max(256, (args.prompt_len + args.steps + args.warmup) // 16 + 8),
                       max_batch_size=args.batch, max_tokens_in_batch=args.batch * args.prompt_len,
                       dtype=args.dtype, fuse_qkv=args.fuse_qkv, use_hip_graph=not args.no_hip_graph,
-                      use_skinny_gemm=args.skinny_gemm)
+                      use_skinny_gemm=args.skinny_gemm, fuse_splitk_consumers=args.splitk_fusion)
     model = LlamaModel(ec)
     model.load_weights()
     # random-init weights of the named architecture: N(0, 0.02^2) matrices, norm weights 1 + N(0, 0.02^2)

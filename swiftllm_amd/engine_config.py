@@ -44,6 +44,8 @@ class EngineConfig:
     # Route decode-sized projections (<= 32 tokens) to the hand-written weight-streaming MFMA GEMM
     # instead of hipBLASLt (prefill-sized calls stay on the BLAS).
     use_skinny_gemm: bool = True
+    # On the skinny-GEMM decode path, let the next kernel sum split-K partial slabs (no reduce launches).
+    fuse_splitk_consumers: bool = True
     # Allocate the host swap pool in pinned memory (true async DMA for swap_blocks).
     pin_swap_memory: bool = True
 

@@ -65,7 +65,7 @@ class LlamaTransformerLayer:
         pure_decode = st.num_prefill_seqs == 0 and st.num_decoding_seqs > 0
         fused_rope_store = (pure_decode and not st.ignore_kvcache and st.position_indices is not None
                             and getattr(ecfg, "fuse_rope_kvstore", False))
-        fast = self.skinny and pure_decode
+        fast = self.skinny and pure_decode and getattr(ecfg, "fuse_splitk_consumers", True)
         if fast and fused_rope_store and w.qkv_proj is not None:
             qkv = linear_splitk(input_embds, w.qkv_proj)
             if isinstance(qkv, SplitKPartials):

@@ -76,6 +76,15 @@ def model_config_dict(name):
     return cfg
 
 
+def ensure_positions(cfg, needed):
+    """Long-context runs on a short-context architecture (BASELINE configs[3]: Llama-2-7B at 16k): linear
+    rope scaling so the rotary table covers the run, as long-context Llama-2 derivatives do."""
+    have = cfg["max_position_embeddings"]
+    if needed + 128 > have:
+        cfg["rope_scaling"] = float(-(-(needed + 128) // have))
+    return cfg
+
+
 def build_model(args, cfg, num_blocks):
     from swiftllm_amd import EngineConfig, LlamaModel
     path = tempfile.mkdtemp(prefix="swl_bench_")
@@ -236,6 +245,7 @@ def main():
     cfg = model_config_dict(args.model)
     B, S = args.batch, args.prompt_len
     gen_total = args.warmup + args.steps
+    ensure_positions(cfg, S + gen_total)
     blocks_per_seq = (S + gen_total + 1 + 15) // 16
     num_blocks = int(B * blocks_per_seq * 1.25) + 8
     model = build_model(args, cfg, num_blocks)

@@ -290,6 +290,12 @@ class LlamaModel:
         _require_hip_device()
         plan = plan_batch(input_ids_list, seq_ids_list, decoding_seq_lens_list,
                           self.model_config.num_kv_heads, self._num_slots)
+        longest = max(plan.seq_lengths_list)
+        if longest > self._cos_cached.shape[0]:
+            # the reference indexes its rope cache out of range here (model.py:350); fail on the host
+            raise RuntimeError(
+                f"sequence length {longest} exceeds the rotary table ({self._cos_cached.shape[0]} positions = "
+                "max_position_embeddings * rope_scaling + 128); use a checkpoint with rope scaling")
         if not ignore_kvcache:
             self.gpu_block_manager.allocate_blocks_for_seqs(seq_ids_list, plan.seq_lengths_list)
         dev = self._upload_plan(plan)

@@ -192,3 +192,14 @@ def test_profile_num_blocks_and_dummy_weights(tmp_path):
     model.init_kvcache_and_swap(min(n, 64))
     toks = model.forward([[1, 2, 3, 4, 5]], [0], [])
     assert len(toks) == 1 and 0 <= toks[0] < cfg["vocab_size"]
+
+
+def test_positions_beyond_the_rope_table_raise_on_the_host(tmp_path):
+    """max_position_embeddings 512 (+128 slack): a 700-token prompt must be refused with a Python
+    exception, not a device memory fault."""
+    cfg = synth.make_config()
+    model = _make_model(tmp_path, cfg, synth.make_state_dict(cfg), 64, max_blocks_per_seq=64,
+                        max_tokens_in_batch=1024)
+    with pytest.raises(RuntimeError, match="rotary table"):
+        model.forward([[1] * 700], [0], [])
+    assert model.forward([[1, 2, 3]], [0], []) is not None

@@ -208,6 +208,14 @@ int swl_gemm_skinny(void *out, const void *x, const void *w, void *workspace, si
                     int32_t M, int32_t N, int32_t K, int64_t x_row_stride, int64_t out_row_stride,
                     int32_t k_splits, int32_t dtype, swl_stream_t stream);
 
+/* FFN up/gate projection with the SiLU-gate fused into the epilogue (reference: transformer_layer.py:126-127
+ * = linear + silu_and_mul_inplace): out[M, I] = (x . W[0:I]^T) * silu(x . W[I:2I]^T), W = [up ; gate]
+ * (weight.py:133). Bit-identical to swl_gemm_skinny(k_splits = 1) + swl_silu_mul. I % 32 == 0,
+ * K % 128 == 0, M <= 32. */
+int swl_gemm_skinny_silu_gate(void *out, const void *x, const void *w_up_gate, int32_t M, int32_t I,
+                              int32_t K, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype,
+                              swl_stream_t stream);
+
 /* Split-K without the reduce launch: the GEMM stops at its fp32 partial slabs [k_splits][M][N] and a FUSED
  * CONSUMER adds them (slab order, one rounding — bit-identical to swl_gemm_skinny's own reduce):
  *   o_proj / down_proj  -> swl_splitk_fused_add_rmsnorm      (reference: rmsnorm.py:39-89)

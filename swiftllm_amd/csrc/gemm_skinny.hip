@@ -35,7 +35,13 @@ __device__ __forceinline__ float16_t mfma32x32x16(vec8_t<bf16> a, vec8_t<bf16> b
 constexpr int kKT = 128;    // k elements per tile (256 bytes per row: two full lines)
 constexpr int kGemmWaves = 4;
 
-template <typename T, bool PARTIAL>
+enum GemmMode {
+    kGemmDirect = 0,   // out[M, N] in T
+    kGemmPartial = 1,  // fp32 slab [ksplit][M][N]
+    kGemmSiluGate = 2, // W = [up ; gate] (2*I rows): out[M, I] = up * silu(gate), the FFN's SiLU-gate fused in
+};
+
+template <typename T, int MODE>
 // 2 waves per SIMD (<= 256 registers): two 4-wave workgroups per CU = 64 KiB of W in flight per CU
 __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_skinny_kernel(
     void *__restrict__ out_, const T *__restrict__ x, const T *__restrict__ w, int M, int N, int K,
@@ -45,8 +51,14 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_skinny_kernel(
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n0 = (blockIdx.x * kGemmWaves + wave) * 32;
-    if (n0 >= N) return; // no barriers in this kernel: a whole wave may leave
+    // SiLU-gate mode: N = I (output columns); waves 0,1 own two `up` tiles, waves 2,3 the `gate`
+    // tiles of the same columns (rows I + ... of W), and hand their activated tile over through LDS.
+    const bool is_gate = MODE == kGemmSiluGate && wave >= 2;
+    const int col0 = MODE == kGemmSiluGate ? (blockIdx.x * 2 + (wave & 1)) * 32
+                                           : (blockIdx.x * kGemmWaves + wave) * 32;
+    const bool tile_ok = col0 < N;
+    if (MODE != kGemmSiluGate && !tile_ok) return; // no barriers in these modes: a whole wave may leave
+    const int n0 = tile_ok ? col0 + (is_gate ? N : 0) : 0; // row of W this wave starts at
     const int ksplit = blockIdx.y;
     const int k_begin = ksplit * kc;
     const int nkt = kc / kKT;
@@ -111,9 +123,39 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_skinny_kernel(
         process(wa, xa);
     }
 
+    if constexpr (MODE == kGemmSiluGate) {
+        // Same rounding points as linear -> silu_and_mul_inplace (reference silu_and_mul.py:16-23): the
+        // projection is rounded to T, silu is evaluated in fp32 and rounded to T, the product is in T.
+        T *xchg = &lds[wave & 1][0][0]; // the `up` partner's W tile: it is done with it only after the barrier
+        T *mine = &lds[wave][0][0];
+        if (is_gate) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float g = to_f(to_t<T>(acc[r]));
+                mine[l32 * 40 + (r & 3) + 8 * (r >> 2) + 4 * hf] = to_t<T>(g / (1.0f + expf(-g)));
+            }
+        }
+        __syncthreads();
+        if (!is_gate && tile_ok && l32 < M) {
+            const T *act = &lds[wave + 2][0][0];
+            typedef T vec4 __attribute__((ext_vector_type(4)));
+            T *o = static_cast<T *>(out_) + static_cast<int64_t>(l32) * out_stride + col0 + 4 * hf;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const vec4 a = *reinterpret_cast<const vec4 *>(act + l32 * 40 + 8 * r4 + 4 * hf);
+                vec4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = mul_t<T>(to_t<T>(acc[4 * r4 + e]), a[e]);
+                *reinterpret_cast<vec4 *>(o + 8 * r4) = v;
+            }
+        }
+        (void)xchg;
+        return;
+    }
+
     // acc[r] = out^T[n = n0 + (r&3) + 8*(r>>2) + 4*hf][m = l32]
     if (l32 < M) {
-        if constexpr (PARTIAL) {
+        if constexpr (MODE == kGemmPartial) {
             float *slab = static_cast<float *>(out_) +
                           (static_cast<int64_t>(ksplit) * M + l32) * N + n0 + 4 * hf;
 #pragma unroll
@@ -182,12 +224,12 @@ static int run_gemm(T *out, const T *x, const T *w, float *ws, size_t ws_bytes, 
     const dim3 grid((tiles + kGemmWaves - 1) / kGemmWaves, ks);
     const int kc = K / ks;
     if (ks == 1) {
-        hipLaunchKernelGGL((gemm_skinny_kernel<T, false>), grid, dim3(kGemmWaves * 64), 0, stream, out, x,
+        hipLaunchKernelGGL((gemm_skinny_kernel<T, kGemmDirect>), grid, dim3(kGemmWaves * 64), 0, stream, out, x,
                            w, M, N, K, kc, xs, os);
         return check_launch();
     }
     if (!ws || ws_bytes < static_cast<size_t>(ks) * M * N * sizeof(float)) return SWL_ERR_BAD_ARG;
-    hipLaunchKernelGGL((gemm_skinny_kernel<T, true>), grid, dim3(kGemmWaves * 64), 0, stream, ws, x, w, M,
+    hipLaunchKernelGGL((gemm_skinny_kernel<T, kGemmPartial>), grid, dim3(kGemmWaves * 64), 0, stream, ws, x, w, M,
                        N, K, kc, xs, static_cast<int64_t>(N));
     if (!reduce) return check_launch();
     const int64_t items = static_cast<int64_t>(M) * (N / 4);
@@ -263,6 +305,31 @@ extern "C" int swl_splitk_reduce(void *out, const float *slabs, int32_t k_splits
         hipLaunchKernelGGL((swl::splitk_reduce_kernel<T>), dim3(grid), dim3(256), 0,
                            static_cast<hipStream_t>(stream), static_cast<T *>(out), slabs, M, N,
                            k_splits, out_row_stride);
+    });
+    return swl::check_launch();
+}
+
+/* FFN up/gate projection with the SiLU-gate fused into the epilogue:
+ * out[M, I] = (x . W[0:I]^T) * silu(x . W[I:2I]^T), W = [up ; gate] as weight.py:133 builds it.
+ * Bit-identical to swl_gemm_skinny (k_splits = 1) followed by swl_silu_mul, minus one launch and the
+ * [M, 2*I] round trip (reference: transformer_layer.py:126-127). I % 32 == 0, K % 128 == 0, M <= 32. */
+extern "C" int swl_gemm_skinny_silu_gate(void *out, const void *x, const void *w_up_gate, int32_t M,
+                                         int32_t I, int32_t K, int64_t x_row_stride,
+                                         int64_t out_row_stride, int32_t dtype, swl_stream_t stream) {
+    if (M < 0 || I <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
+    if (M == 0) return SWL_OK;
+    if (!out || !x || !w_up_gate) return SWL_ERR_BAD_ARG;
+    if (M > 32 || (I & 31) || (K & (swl::kKT - 1))) return SWL_ERR_UNSUPPORTED;
+    if (x_row_stride < K || out_row_stride < I || (x_row_stride & 7) || (out_row_stride & 3))
+        return SWL_ERR_BAD_ARG;
+    if (!swl::aligned16(x) || !swl::aligned16(w_up_gate) || (reinterpret_cast<uintptr_t>(out) & 7u))
+        return SWL_ERR_BAD_ARG;
+    const dim3 grid((I / 32 + 1) / 2, 1);
+    SWL_DISPATCH_DTYPE(dtype, T, {
+        hipLaunchKernelGGL((swl::gemm_skinny_kernel<T, swl::kGemmSiluGate>), grid,
+                           dim3(swl::kGemmWaves * 64), 0, static_cast<hipStream_t>(stream), out,
+                           static_cast<const T *>(x), static_cast<const T *>(w_up_gate), M, I, K, K,
+                           x_row_stride, out_row_stride);
     });
     return swl::check_launch();
 }

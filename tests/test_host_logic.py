@@ -266,3 +266,16 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f), encoding="utf-8").read()
                 assert "import oracle" not in text and "from oracle" not in text, os.path.join(dirpath, f)
+
+
+def test_swiftllm_alias_resolves_to_this_implementation():
+    import swiftllm
+    import swiftllm_amd
+    import swiftllm.worker.model as aliased
+    import swiftllm_amd.worker.model as real
+    from swiftllm.worker.kernels.paged_attn import paged_attention
+    assert aliased is real and swiftllm.LlamaModel is swiftllm_amd.LlamaModel
+    assert swiftllm.EngineConfig is swiftllm_amd.EngineConfig
+    assert paged_attention.__module__ == "swiftllm_amd.worker.kernels.paged_attn"
+    with pytest.raises(ImportError):
+        import swiftllm.no_such_module  # noqa: F401

@@ -1,0 +1,102 @@
+"""Request-sharded data parallelism for serving: N independent replicas on the N GPUs of one node.
+
+    python -m swiftllm_amd.server.router --num-replicas 8 --model-path DIR [--port 8000] [engine flags]
+
+Each replica is an `api_server` process pinned to one GPU (HIP_VISIBLE_DEVICES=i, so it sees its GPU as
+device 0 like a single-GPU run) with its own weights, KV pool and scheduler. This process only routes:
+a request goes to the replica with the fewest outstanding tokens and stays there for its whole life —
+no KV migration, no collective, nothing on xGMI (the reference has no multi-GPU mode).
+"""
+import argparse
+import asyncio
+import json
+import os
+import subprocess
+import sys
+from typing import List
+
+from swiftllm_amd import dp
+
+
+class ReplicaRouter:
+    """Least-outstanding-tokens routing over a fixed set of replica URLs (pure bookkeeping)."""
+
+    def __init__(self, urls: List[str]):
+        self.urls = list(urls)
+        self.outstanding = [0] * len(urls)
+
+    def acquire(self, cost: int) -> int:
+        i = dp.least_loaded(self.outstanding)
+        self.outstanding[i] += cost
+        return i
+
+    def release(self, i: int, cost: int):
+        self.outstanding[i] -= cost
+
+
+def request_cost(body: dict) -> int:
+    ids = body.get("prompt_token_ids")
+    return int(body.get("output_len", 0)) + (len(ids) if ids else len(str(body.get("prompt", "")).split()))
+
+
+def build_app(router: ReplicaRouter):
+    import aiohttp
+    import fastapi
+    from fastapi.responses import JSONResponse, StreamingResponse
+    app = fastapi.FastAPI()
+
+    @app.post("/generate")
+    async def generate(req: fastapi.Request):
+        body = await req.json()
+        cost = request_cost(body)
+        i = router.acquire(cost)
+        url = router.urls[i] + "/generate"
+        if body.get("stream", False):
+            async def relay():
+                try:
+                    async with aiohttp.ClientSession() as s, s.post(url, json=body) as r:
+                        async for chunk in r.content.iter_any():
+                            yield chunk
+                finally:
+                    router.release(i, cost)
+            return StreamingResponse(relay(), media_type="text/plain")
+        try:
+            async with aiohttp.ClientSession() as s, s.post(url, json=body) as r:
+                return JSONResponse(await r.json(), status_code=r.status)
+        finally:
+            router.release(i, cost)
+
+    @app.get("/load")
+    async def load():
+        return JSONResponse({"outstanding_tokens": router.outstanding})
+
+    return app
+
+
+def spawn_replicas(num: int, base_port: int, passthrough: List[str]) -> List[subprocess.Popen]:
+    procs = []
+    for i in range(num):
+        env = dict(os.environ, HIP_VISIBLE_DEVICES=str(i), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, "-m", "swiftllm_amd.server.api_server", "--port", str(base_port + 1 + i)] + passthrough
+        procs.append(subprocess.Popen(cmd, env=env))
+    return procs
+
+
+def main():
+    ap = argparse.ArgumentParser(description="swiftllm_amd replica router (request-sharded DP)")
+    ap.add_argument("--num-replicas", type=int, default=8)
+    ap.add_argument("--host", default="127.0.0.1")
+    ap.add_argument("--port", type=int, default=8000)
+    args, passthrough = ap.parse_known_args()
+    procs = spawn_replicas(args.num_replicas, args.port, passthrough)
+    router = ReplicaRouter([f"http://127.0.0.1:{args.port + 1 + i}" for i in range(args.num_replicas)])
+    try:
+        import uvicorn
+        uvicorn.run(build_app(router), host=args.host, port=args.port, log_level="warning")
+    finally:
+        for p in procs:
+            p.terminate()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,203 @@
+"""Control plane on CPU: scheduler policy, engine loop (with a fake data plane), HTTP layer, router."""
+import asyncio
+import types
+
+import pytest
+
+from swiftllm_amd.engine_config import EngineConfig
+from swiftllm_amd.server import Engine, RawRequest, Request, Scheduler, RequestIdManager
+from swiftllm_amd.server.router import ReplicaRouter, request_cost
+
+
+def _cfg(**kw):
+    base = dict(model_path="", use_dummy=True, block_size=16, gpu_mem_utilization=0.9, num_cpu_blocks=64,
+                max_seqs_in_block_table=16, max_blocks_per_seq=64, max_batch_size=4, max_tokens_in_batch=100)
+    base.update(kw)
+    return EngineConfig(**base)
+
+
+def _req(prompt_len, output_len=4):
+    return Request(RawRequest("", output_len, list(range(prompt_len))))
+
+
+def test_request_id_manager():
+    m = RequestIdManager(3)
+    assert [m.get_id(), m.get_id(), m.get_id()] == [0, 1, 2]
+    with pytest.raises(RuntimeError, match="max_seqs_in_block_table"):
+        m.get_id()
+    m.free_ids([1])
+    assert m.get_id() == 1
+
+
+def test_scheduler_fcfs_admission_budgets():
+    s = Scheduler(None, _cfg(), num_gpu_blocks=10)
+    reqs = [_req(40), _req(40), _req(40), _req(5)]
+    s.on_requests_arrival(reqs)
+    batch, sin, sout = s.get_next_batch()
+    # 40+40 = 80 tokens fit max_tokens_in_batch=100, the third prompt does not — and the short one
+    # behind it must NOT overtake (strict FCFS)
+    assert batch == reqs[:2] and sin == [] and sout == []
+    assert [r.request_id for r in batch] == [0, 1]
+    for r in batch:
+        r.output_token_ids.append(1)
+    s.on_batch_finish(batch)
+    batch2, _, _ = s.get_next_batch()
+    assert batch2 == reqs[2:4]              # 3+3 blocks running, 3+1 more fit in 10
+    assert s.get_next_batch()[0] == s.running_q     # nothing waiting: decode everyone
+
+
+def test_scheduler_swaps_out_newest_and_back_in_oldest_first():
+    s = Scheduler(None, _cfg(max_tokens_in_batch=1000), num_gpu_blocks=4)
+    a, b = _req(31, 40), _req(31, 40)      # 2 blocks each: the pool is exactly full
+    s.on_requests_arrival([a, b])
+    batch, _, _ = s.get_next_batch()
+    assert batch == [a, b]
+    for r in (a, b):
+        r.output_token_ids.append(7)
+    s.on_batch_finish(batch)
+    batch, sin, sout = s.get_next_batch()   # 32 tokens each: still 2 blocks
+    assert (batch, sin, sout) == ([a, b], [], [])
+    for r in (a, b):
+        r.output_token_ids.append(7)        # 33 tokens -> 3 blocks each > 4 in total
+    s.on_batch_finish(batch)
+    batch, sin, sout = s.get_next_batch()
+    assert batch == [a] and sout == [b] and sin == []
+    assert list(s.swapped_q) == [b]
+    c = _req(5)
+    s.on_requests_arrival([c])              # no new prompt while something is swapped out
+    a.output_token_ids.extend([7] * 38)     # a finishes
+    s.on_batch_finish([a])
+    batch, sin, sout = s.get_next_batch()
+    assert sin == [b] and batch == [b] and sout == []
+    assert list(s.waiting_q) == [c]
+    assert isinstance(sout, list)           # an empty list is falsy: the idle engine can sleep
+
+
+def test_scheduler_piggyback_mixes_prefill_and_decode():
+    s = Scheduler(None, _cfg(max_tokens_in_batch=64), num_gpu_blocks=100, piggyback=True)
+    a = _req(10)
+    s.on_requests_arrival([a])
+    s.get_next_batch()
+    a.output_token_ids.append(3)
+    s.on_batch_finish([a])
+    b = _req(20)
+    s.on_requests_arrival([b])
+    batch, _, _ = s.get_next_batch()
+    assert batch == [b, a]                  # prefill first, then the riding decode
+    assert b.is_prefill_stage() and not a.is_prefill_stage()
+    plain = Scheduler(None, _cfg(max_tokens_in_batch=64), num_gpu_blocks=100)
+    plain.running_q.append(a)
+    plain.on_requests_arrival([_req(20)])
+    assert len(plain.get_next_batch()[0]) == 1     # the reference's behaviour: prefill alone
+
+
+class FakeModel:
+    """The four calls the engine makes, with deterministic tokens: next = (sum of inputs + position) % 97."""
+    num_blocks = 8
+
+    def __init__(self):
+        self.model_config = types.SimpleNamespace()
+        self.calls = []
+        self.freed = []
+
+    def forward(self, input_ids, seq_ids, decoding_lens):
+        n_prefill = len(input_ids) - len(decoding_lens)
+        assert all(len(x) == 1 for x in input_ids[n_prefill:])
+        self.calls.append((n_prefill, len(decoding_lens)))
+        lens = [len(x) for x in input_ids[:n_prefill]] + list(decoding_lens)
+        return [(sum(ids) + n) % 97 for ids, n in zip(input_ids, lens)]
+
+    def swap_in_seqs(self, ids):
+        self.calls.append(("in", list(ids)))
+
+    def swap_out_seqs(self, ids):
+        self.calls.append(("out", list(ids)))
+
+    def free_seqs_resources(self, ids):
+        self.freed.extend(ids)
+
+
+def _expected(prompt, n):
+    out, last, length = [], None, len(prompt)
+    for i in range(n):
+        if i == 0:
+            tok = (sum(prompt) + length) % 97
+        else:
+            length += 1
+            tok = (last + length) % 97
+        out.append(tok)
+        last = tok
+    return out
+
+
+@pytest.mark.parametrize("piggyback", [False, True])
+def test_engine_generates_streams_and_frees(piggyback):
+    async def run():
+        model = FakeModel()
+        eng = Engine(_cfg(max_batch_size=3), model=model, piggyback=piggyback)
+        await eng.initialize()
+        loops = asyncio.ensure_future(eng.start_all_event_loops())
+        prompts = [[5, 6, 7], [1], [9, 9, 9, 9], [2, 3]]
+        waits = [asyncio.ensure_future(eng.add_request_and_wait(RawRequest("", n, p)))
+                 for n, p in zip((3, 6, 7), prompts[:3])]
+
+        async def stream(p):
+            return [s.token_id async for s in eng.add_request_and_stream(RawRequest("", 4, p))]
+        streamed = asyncio.ensure_future(stream(prompts[3]))
+        done = await asyncio.wait_for(asyncio.gather(*waits, streamed), timeout=20)
+        loops.cancel()
+        return model, done
+    model, done = asyncio.run(run())
+    for (req, toks), p, n in zip(done[:3], [[5, 6, 7], [1], [9, 9, 9, 9]], (3, 6, 7)):
+        assert toks == _expected(p, n) and req.is_finished()
+    assert done[3] == _expected([2, 3], 4)
+    assert len(model.freed) == 4            # every request freed exactly once
+    if piggyback:
+        assert any(isinstance(c[0], int) and c[0] > 0 and c[1] > 0 for c in model.calls)   # a mixed batch happened
+    else:
+        assert all(not (isinstance(c[0], int) and c[0] > 0 and c[1] > 0) for c in model.calls)
+
+
+def test_engine_idles_without_calling_the_model():
+    async def run():
+        model = FakeModel()
+        eng = Engine(_cfg(), model=model)
+        await eng.initialize()
+        assert await eng.step() is False
+        return model
+    assert asyncio.run(run()).calls == []
+
+
+def test_api_server_generate_endpoint():
+    from fastapi.testclient import TestClient
+    from swiftllm_amd.server.api_server import build_app
+
+    async def boot():
+        eng = Engine(_cfg(), model=FakeModel())
+        await eng.initialize()
+        return eng
+    loop = asyncio.new_event_loop()
+    eng = loop.run_until_complete(boot())
+    app = build_app(eng)
+
+    @app.on_event("startup")
+    async def start_loops():
+        eng.event_loop = asyncio.get_running_loop()
+        asyncio.ensure_future(eng.start_all_event_loops())
+    with TestClient(app) as client:
+        r = client.post("/generate", json={"prompt_token_ids": [4, 5], "output_len": 3})
+        assert r.status_code == 200 and r.json() == {"output_token_ids": _expected([4, 5], 3)}
+        r = client.post("/generate", json={"prompt_token_ids": [8], "output_len": 4, "stream": True})
+        assert [int(x) for x in r.text.split()] == _expected([8], 4)
+        assert client.get("/load").json() == {"outstanding_tokens": 0}
+
+
+def test_replica_router_balances_by_outstanding_tokens():
+    r = ReplicaRouter([f"http://x:{i}" for i in range(4)])
+    picks = [r.acquire(c) for c in (100, 10, 10, 10, 10, 10)]
+    assert picks[:4] == [0, 1, 2, 3]
+    assert picks[4] == 1 and picks[5] == 2      # the heavy replica is avoided
+    r.release(0, 100)
+    assert r.acquire(1) == 0
+    assert request_cost({"prompt_token_ids": [1, 2, 3], "output_len": 7}) == 10
+    assert request_cost({"prompt": "a b c d", "output_len": 1}) == 5

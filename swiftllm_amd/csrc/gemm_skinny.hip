@@ -18,6 +18,12 @@
 //     LDS it wrote itself;
 //   * the NEXT K-tile (8 KiB of W + 8 KiB of x per wave) is in flight in registers while the current
 //     one is transposed and multiplied (branch-free steady state => counted vmcnt waits);
+//   * long K-chunks (>= 8 tiles) run the RING variant below: the x tile is shared by the four waves of
+//     the workgroup (each stages a quarter; one barrier per K-tile) and W tiles ride a 3-deep register
+//     ring. Measured on MI355X (tools/probe/, bf16, M = 32): per-wave x tiles cost 10-15 % of the
+//     stream rate (4.7 -> 5.4 TB/s with the x traffic removed); the ring variant recovers most of it
+//     (up_gate 46.2 -> 43.0 us, lm_head 199 -> 189 us, down 22.5 -> 21.1 us). Short chunks (o_proj:
+//     4 tiles per wave) are better off without barriers and keep the private-tile kernel;
 //   * N/32 tiles alone do not fill 256 CUs for N = 4096..6144, so K is split across workgroups
 //     (grid.y): each split writes an fp32 partial slab, a second tiny kernel adds the slabs in a fixed
 //     order and rounds once. Deterministic, no atomics.
@@ -40,6 +46,64 @@ enum GemmMode {
     kGemmPartial = 1,  // fp32 slab [ksplit][M][N]
     kGemmSiluGate = 2, // W = [up ; gate] (2*I rows): out[M, I] = up * silu(gate), the FFN's SiLU-gate fused in
 };
+
+// acc[r] = out^T[n = n0 + (r&3) + 8*(r>>2) + 4*hf][m = l32] -> the three output modes.
+// `wtiles + w * wave_pitch` is wave w's private W tile (reused as exchange space in SiLU-gate mode).
+template <typename T, int MODE>
+__device__ __forceinline__ void gemm_epilogue(const float16_t &acc, void *__restrict__ out_, T *wtiles,
+                                              int wave_pitch, int wave, int lane, bool is_gate, bool tile_ok,
+                                              int col0, int n0, int ksplit, int M, int N, int64_t out_stride) {
+    const int l32 = lane & 31;
+    const int hf = lane >> 5;
+    if constexpr (MODE == kGemmSiluGate) {
+        // Same rounding points as linear -> silu_and_mul_inplace (reference silu_and_mul.py:16-23): the
+        // projection is rounded to T, silu is evaluated in fp32 and rounded to T, the product is in T.
+        T *mine = wtiles + wave * wave_pitch;
+        if (is_gate) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float g = to_f(to_t<T>(acc[r]));
+                mine[l32 * 40 + (r & 3) + 8 * (r >> 2) + 4 * hf] = to_t<T>(g / (1.0f + expf(-g)));
+            }
+        }
+        __syncthreads();
+        if (!is_gate && tile_ok && l32 < M) {
+            const T *act = wtiles + (wave + 2) * wave_pitch;
+            typedef T vec4 __attribute__((ext_vector_type(4)));
+            T *o = static_cast<T *>(out_) + static_cast<int64_t>(l32) * out_stride + col0 + 4 * hf;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const vec4 a = *reinterpret_cast<const vec4 *>(act + l32 * 40 + 8 * r4 + 4 * hf);
+                vec4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = mul_t<T>(to_t<T>(acc[4 * r4 + e]), a[e]);
+                *reinterpret_cast<vec4 *>(o + 8 * r4) = v;
+            }
+        }
+        return;
+    }
+    if (tile_ok && l32 < M) {
+        if constexpr (MODE == kGemmPartial) {
+            float *slab = static_cast<float *>(out_) +
+                          (static_cast<int64_t>(ksplit) * M + l32) * N + n0 + 4 * hf;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4_t v = {acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]};
+                *reinterpret_cast<float4_t *>(slab + 8 * r4) = v;
+            }
+        } else {
+            typedef T vec4 __attribute__((ext_vector_type(4)));
+            T *o = static_cast<T *>(out_) + static_cast<int64_t>(l32) * out_stride + n0 + 4 * hf;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                vec4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = to_t<T>(acc[4 * r4 + e]);
+                *reinterpret_cast<vec4 *>(o + 8 * r4) = v;
+            }
+        }
+    }
+}
 
 template <typename T, int MODE>
 // 2 waves per SIMD (<= 256 registers): two 4-wave workgroups per CU = 64 KiB of W in flight per CU
@@ -123,58 +187,117 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_skinny_kernel(
         process(wa, xa);
     }
 
-    if constexpr (MODE == kGemmSiluGate) {
-        // Same rounding points as linear -> silu_and_mul_inplace (reference silu_and_mul.py:16-23): the
-        // projection is rounded to T, silu is evaluated in fp32 and rounded to T, the product is in T.
-        T *xchg = &lds[wave & 1][0][0]; // the `up` partner's W tile: it is done with it only after the barrier
-        T *mine = &lds[wave][0][0];
-        if (is_gate) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float g = to_f(to_t<T>(acc[r]));
-                mine[l32 * 40 + (r & 3) + 8 * (r >> 2) + 4 * hf] = to_t<T>(g / (1.0f + expf(-g)));
-            }
-        }
-        __syncthreads();
-        if (!is_gate && tile_ok && l32 < M) {
-            const T *act = &lds[wave + 2][0][0];
-            typedef T vec4 __attribute__((ext_vector_type(4)));
-            T *o = static_cast<T *>(out_) + static_cast<int64_t>(l32) * out_stride + col0 + 4 * hf;
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const vec4 a = *reinterpret_cast<const vec4 *>(act + l32 * 40 + 8 * r4 + 4 * hf);
-                vec4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = mul_t<T>(to_t<T>(acc[4 * r4 + e]), a[e]);
-                *reinterpret_cast<vec4 *>(o + 8 * r4) = v;
-            }
-        }
-        (void)xchg;
-        return;
-    }
+    gemm_epilogue<T, MODE>(acc, out_, &lds[0][0][0], 2 * 32 * kKT, wave, lane, is_gate, tile_ok, col0, n0,
+                           ksplit, M, N, out_stride);
+}
 
-    // acc[r] = out^T[n = n0 + (r&3) + 8*(r>>2) + 4*hf][m = l32]
-    if (l32 < M) {
-        if constexpr (MODE == kGemmPartial) {
-            float *slab = static_cast<float *>(out_) +
-                          (static_cast<int64_t>(ksplit) * M + l32) * N + n0 + 4 * hf;
+// ---- RING variant: x tile shared by the workgroup, kRing-deep register ring of W tiles --------------
+constexpr int kRing = 3;
+
+template <typename T, int MODE>
+// 2 waves per SIMD: the ring holds 3 x 8 KiB of W per wave in registers (~220 VGPRs)
+__global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_skinny_ring_kernel(
+    void *__restrict__ out_, const T *__restrict__ x, const T *__restrict__ w, int M, int N, int K,
+    int kc, int64_t x_stride, int64_t out_stride) {
+    constexpr int D = kRing;
+    constexpr int XL = 8 / kGemmWaves; // x row-groups (4 rows each) a wave stages per tile
+    // [0..1] the double-buffered x tile of the workgroup, [2 + wave] the wave-private W tile
+    __shared__ __attribute__((aligned(16))) T lds[2 + kGemmWaves][32 * kKT];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool is_gate = MODE == kGemmSiluGate && wave >= 2;
+    const int col0 = MODE == kGemmSiluGate ? (blockIdx.x * 2 + (wave & 1)) * 32
+                                           : (blockIdx.x * kGemmWaves + wave) * 32;
+    const bool tile_ok = col0 < N; // barriers below: a wave without a tile still stages x and syncs
+    const int n0 = tile_ok ? col0 + (is_gate ? N : 0) : 0;
+    const int ksplit = blockIdx.y;
+    const int k_begin = ksplit * kc;
+    const int nkt = kc / kKT;
+
+    const int rsub = lane >> 4;
+    const int chunk = lane & 15;
+    const T *wsrc = w + static_cast<int64_t>(n0 + rsub) * K + k_begin + chunk * 8;
+    int lds_wr[8];
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const float4_t v = {acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]};
-                *reinterpret_cast<float4_t *>(slab + 8 * r4) = v;
-            }
-        } else {
-            typedef T vec4 __attribute__((ext_vector_type(4)));
-            T *o = static_cast<T *>(out_) + static_cast<int64_t>(l32) * out_stride + n0 + 4 * hf;
+    for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + rsub;
+        lds_wr[i] = row * kKT + ((chunk ^ (row & 15)) << 3);
+    }
+    const T *xsrc[XL];
+    int xs_wr[XL];
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                vec4 v;
+    for (int q = 0; q < XL; ++q) {
+        const int row = 4 * (wave * XL + q) + rsub;
+        xsrc[q] = x + static_cast<int64_t>(min(row, M - 1)) * x_stride + k_begin + chunk * 8;
+        xs_wr[q] = row * kKT + ((chunk ^ (row & 15)) << 3);
+    }
+    const int l32 = lane & 31;
+    const int hf = lane >> 5;
+    T *wl = &lds[2 + wave][0];
+
+    vec8_t<T> wr[D][8], xr[D][XL];
+    float16_t acc = float16_t{};
+    // x loads go first: they are the ones the stage-ahead below waits for (loads return in order)
+#define SWL_ISSUE(slot, tile)                                                                        \
+    {                                                                                                \
+        _Pragma("unroll") for (int q_ = 0; q_ < XL; ++q_) xr[slot][q_] = load8(xsrc[q_] + (tile) * kKT); \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                             \
+            wr[slot][i_] = load8_nt(wsrc + static_cast<int64_t>(4 * i_) * K + (tile) * kKT);         \
+    }
+#define SWL_STAGE_X(slot, buf)                                                                       \
+    {                                                                                                \
+        _Pragma("unroll") for (int q_ = 0; q_ < XL; ++q_)                                            \
+            *reinterpret_cast<vec8_t<T> *>(&lds[buf][xs_wr[q_]]) = xr[slot][q_];                     \
+    }
+#define SWL_PROCESS(slot, buf)                                                                       \
+    {                                                                                                \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                             \
+            *reinterpret_cast<vec8_t<T> *>(wl + lds_wr[i_]) = wr[slot][i_];                          \
+        const T *xl_ = &lds[buf][0];                                                                 \
+        _Pragma("unroll") for (int kk_ = 0; kk_ < kKT / 16; ++kk_) {                                 \
+            const int off_ = l32 * kKT + (((2 * kk_ + hf) ^ (l32 & 15)) << 3);                       \
+            const vec8_t<T> a_ = *reinterpret_cast<const vec8_t<T> *>(wl + off_);                    \
+            const vec8_t<T> b_ = *reinterpret_cast<const vec8_t<T> *>(xl_ + off_);                   \
+            acc = mfma32x32x16(a_, b_, acc);                                                         \
+        }                                                                                            \
+    }
+    // prologue: D-1 tiles in flight (the host guarantees nkt >= D-1); x of tile 0 published
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = to_t<T>(acc[4 * r4 + e]);
-                *reinterpret_cast<vec4 *>(o + 8 * r4) = v;
+    for (int d = 0; d < D - 1; ++d) SWL_ISSUE(d, d);
+    SWL_STAGE_X(0, 0);
+    __syncthreads();
+    int kt = 0;
+    // steady state, branch-free (counted vmcnt waits): step d multiplies tile kt+d out of slot d, refills
+    // slot (d+D-1)%D with tile kt+d+D-1 and publishes the x tile of kt+d+1 (in the other x buffer: its
+    // last readers finished before the previous barrier)
+    for (; kt + 2 * D - 1 <= nkt; kt += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            SWL_ISSUE((d + D - 1) % D, kt + d + D - 1);
+            SWL_PROCESS(d, (kt + d) & 1);
+            SWL_STAGE_X((d + 1) % D, (kt + d + 1) & 1);
+            __syncthreads();
+        }
+    }
+    // drain: D-1 .. 2D-2 tiles left, the first D-1 of them in flight in slots 0..D-2
+    const int rem = nkt - kt;
+#pragma unroll
+    for (int t = 0; t < 2 * D - 2; ++t) {
+        if (t < rem) {
+            if (t + D - 1 < rem) SWL_ISSUE((t + D - 1) % D, kt + t + D - 1);
+            SWL_PROCESS(t % D, (kt + t) & 1);
+            if (t + 1 < rem) {
+                SWL_STAGE_X((t + 1) % D, (kt + t + 1) & 1);
+                __syncthreads();
             }
         }
     }
+#undef SWL_ISSUE
+#undef SWL_STAGE_X
+#undef SWL_PROCESS
+    gemm_epilogue<T, MODE>(acc, out_, &lds[2][0], 32 * kKT, wave, lane, is_gate, tile_ok, col0, n0, ksplit, M,
+                           N, out_stride);
 }
 
 // out[m][n] = round(sum over splits, in split order) — 4 outputs per thread.
@@ -214,6 +337,9 @@ static int choose_k_splits(int N, int K) {
     return ks;
 }
 
+// K-chunks of >= 8 tiles amortise the ring's barriers; shorter ones keep the barrier-free kernel.
+static bool use_ring(int kc) { return kc / kKT >= 8; }
+
 // reduce == false: stop after the partial slabs (a fused consumer sums them: swl_splitk_*)
 template <typename T>
 static int run_gemm(T *out, const T *x, const T *w, float *ws, size_t ws_bytes, int M, int N, int K,
@@ -223,14 +349,23 @@ static int run_gemm(T *out, const T *x, const T *w, float *ws, size_t ws_bytes, 
     const int tiles = N / 32;
     const dim3 grid((tiles + kGemmWaves - 1) / kGemmWaves, ks);
     const int kc = K / ks;
+    const bool ring = use_ring(kc);
     if (ks == 1) {
-        hipLaunchKernelGGL((gemm_skinny_kernel<T, kGemmDirect>), grid, dim3(kGemmWaves * 64), 0, stream, out, x,
-                           w, M, N, K, kc, xs, os);
+        if (ring)
+            hipLaunchKernelGGL((gemm_skinny_ring_kernel<T, kGemmDirect>), grid, dim3(kGemmWaves * 64), 0, stream,
+                               out, x, w, M, N, K, kc, xs, os);
+        else
+            hipLaunchKernelGGL((gemm_skinny_kernel<T, kGemmDirect>), grid, dim3(kGemmWaves * 64), 0, stream, out,
+                               x, w, M, N, K, kc, xs, os);
         return check_launch();
     }
     if (!ws || ws_bytes < static_cast<size_t>(ks) * M * N * sizeof(float)) return SWL_ERR_BAD_ARG;
-    hipLaunchKernelGGL((gemm_skinny_kernel<T, kGemmPartial>), grid, dim3(kGemmWaves * 64), 0, stream, ws, x, w, M,
-                       N, K, kc, xs, static_cast<int64_t>(N));
+    if (ring)
+        hipLaunchKernelGGL((gemm_skinny_ring_kernel<T, kGemmPartial>), grid, dim3(kGemmWaves * 64), 0, stream, ws,
+                           x, w, M, N, K, kc, xs, static_cast<int64_t>(N));
+    else
+        hipLaunchKernelGGL((gemm_skinny_kernel<T, kGemmPartial>), grid, dim3(kGemmWaves * 64), 0, stream, ws, x, w,
+                           M, N, K, kc, xs, static_cast<int64_t>(N));
     if (!reduce) return check_launch();
     const int64_t items = static_cast<int64_t>(M) * (N / 4);
     const unsigned rgrid = static_cast<unsigned>((items + 255) / 256);
@@ -326,10 +461,16 @@ extern "C" int swl_gemm_skinny_silu_gate(void *out, const void *x, const void *w
         return SWL_ERR_BAD_ARG;
     const dim3 grid((I / 32 + 1) / 2, 1);
     SWL_DISPATCH_DTYPE(dtype, T, {
-        hipLaunchKernelGGL((swl::gemm_skinny_kernel<T, swl::kGemmSiluGate>), grid,
-                           dim3(swl::kGemmWaves * 64), 0, static_cast<hipStream_t>(stream), out,
-                           static_cast<const T *>(x), static_cast<const T *>(w_up_gate), M, I, K, K,
-                           x_row_stride, out_row_stride);
+        if (swl::use_ring(K))
+            hipLaunchKernelGGL((swl::gemm_skinny_ring_kernel<T, swl::kGemmSiluGate>), grid,
+                               dim3(swl::kGemmWaves * 64), 0, static_cast<hipStream_t>(stream), out,
+                               static_cast<const T *>(x), static_cast<const T *>(w_up_gate), M, I, K, K,
+                               x_row_stride, out_row_stride);
+        else
+            hipLaunchKernelGGL((swl::gemm_skinny_kernel<T, swl::kGemmSiluGate>), grid,
+                               dim3(swl::kGemmWaves * 64), 0, static_cast<hipStream_t>(stream), out,
+                               static_cast<const T *>(x), static_cast<const T *>(w_up_gate), M, I, K, K,
+                               x_row_stride, out_row_stride);
     });
     return swl::check_launch();
 }

@@ -455,7 +455,9 @@ def test_swap_blocks_round_trip(pinned):
 # ---- skinny GEMM --------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M", [1, 5, 32])
-@pytest.mark.parametrize("N,K", [(4096, 4096), (6144, 4096), (28672, 4096), (4096, 14336), (128, 128), (256, 256), (512, 1024), (96, 384)])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (6144, 4096), (28672, 4096), (4096, 14336), (128, 128), (256, 256), (512, 1024), (96, 384),
+                                 # ring kernel (>= 8 K-tiles per chunk): every drain remainder, ragged last workgroup
+                                 (160, 1152), (160, 1280), (96, 1408), (64, 1536), (32, 2048 + 128)])
 def test_gemm_skinny_vs_fp32_reference(dtype, M, N, K):
     """out = round(x @ W^T) with fp32 accumulation: agreement with an fp32 matmul to one rounding of the
     storage dtype (summation order differs), for every k-split the kernel offers."""
@@ -557,7 +559,8 @@ def test_splitk_rotary_store_equals_unfused(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,I,Kd", [(32, 14336, 4096), (7, 11008, 4096), (1, 256, 128), (32, 96, 384)])
+@pytest.mark.parametrize("M,I,Kd", [(32, 14336, 4096), (7, 11008, 4096), (1, 256, 128), (32, 96, 384),
+                                    (9, 96, 1152), (32, 160, 1280)])
 def test_gemm_silu_gate_fusion_equals_two_ops(dtype, M, I, Kd):
     """linear_silu_gate == skinny linear (one k-split) followed by silu_and_mul, bit for bit."""
     from swiftllm_amd import _hip

@@ -102,6 +102,14 @@ int swl_store_kv_decode(void *k_cache, void *v_cache, const void *k, const void 
 int swl_silu_mul(void *x, int64_t num_tokens, int32_t ffn_inter_dim, int32_t dtype,
                  swl_stream_t stream);
 
+/* ---- Greedy sampling --------------------------------------------------------------------------
+ * reference: post_layer.py:40 (`torch.argmax(logits, dim=1)`)
+ * out[r] = argmax_j x[r, j] (int64), ties -> lowest j, NaNs never selected. n % 8 == 0.
+ * scratch: swl_argmax_scratch_bytes(num_rows) bytes, 16-byte aligned. */
+size_t swl_argmax_scratch_bytes(int64_t num_rows);
+int swl_argmax(int64_t *out, const void *x, void *scratch, size_t scratch_bytes, int64_t num_rows, int32_t n,
+               int64_t row_stride, int32_t dtype, swl_stream_t stream);
+
 /* ---- Paged attention, decode (flash-decoding, "paged attention v2") --------------------------
  * reference: paged_attn.py:9-108 (phase 1), :111-149 (phase 2), launcher :152-222
  * q[Bd, H, D] (token stride q_tok_stride), o[Bd, H, D] (token stride o_tok_stride).

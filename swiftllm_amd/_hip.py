@@ -38,6 +38,7 @@ SIGNATURES = {
     "swl_store_kv_decode": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32,
                             _I64, _I64, _I32, _P],
     "swl_silu_mul": [_P, _I64, _I32, _I32, _P],
+    "swl_argmax": [_P, _P, _P, ctypes.c_size_t, _I64, _I32, _I64, _I32, _P],
     "swl_paged_attn_decode": [_P, _P, _P, _P, _P, _P, _P, _P, _F32, _I32, _I32, _I32, _I32, _I32,
                               _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I32, _P],
     "swl_paged_attn_phase1": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F32, _I32, _I32, _I32, _I32,
@@ -65,6 +66,7 @@ _SPECIAL = {
     "swl_abi_version": ([], _I32),
     "swl_strerror": ([_I32], ctypes.c_char_p),
     "swl_paged_attn_scratch_bytes": ([_I32, _I32, _I32, _I32], ctypes.c_size_t),
+    "swl_argmax_scratch_bytes": ([_I64], ctypes.c_size_t),
     "swl_gemm_skinny_workspace_bytes": ([_I32, _I32, _I32], ctypes.c_size_t),
     "swl_gemm_skinny_choose_splits": ([_I32, _I32], _I32),
 }

@@ -82,7 +82,9 @@ __global__ __launch_bounds__(256) void rotary_store_decode_kernel(
     const int chunks = D >> 4;
     const int rot_items = (H + KVH) * chunks;
     const int v_items = KVH * (D >> 3);
-    for (int item = threadIdx.x; item < rot_items + v_items; item += 256) {
+    // one item per thread: grid.y workgroups share a token, so the (latency-bound) load -> rotate ->
+    // store chain is walked once, not once per 256 items
+    for (int item = blockIdx.y * 256 + threadIdx.x; item < rot_items + v_items; item += gridDim.y * 256) {
         if (item < rot_items) {
             const int c = item % chunks;
             const int hh = item / chunks;
@@ -188,7 +190,9 @@ static int rotary_store_decode_impl(
     const int64_t slab_stride = static_cast<int64_t>(num_decoding_seqs) *
                                 (num_q_heads + 2 * num_kv_heads) * head_dim;
     SWL_DISPATCH_DTYPE(dtype, T, {
-        hipLaunchKernelGGL((swl::rotary_store_decode_kernel<T>), dim3(num_decoding_seqs), dim3(256),
+        const int items = (num_q_heads + num_kv_heads) * (head_dim / 16) + num_kv_heads * (head_dim / 8);
+        const int wgs_per_token = items > 2048 ? 8 : (items + 255) / 256;
+        hipLaunchKernelGGL((swl::rotary_store_decode_kernel<T>), dim3(num_decoding_seqs, wgs_per_token), dim3(256),
                            0, static_cast<hipStream_t>(stream), static_cast<T *>(q),
                            static_cast<T *>(k), static_cast<const T *>(v),
                            static_cast<const T *>(cos_table), static_cast<const T *>(sin_table),

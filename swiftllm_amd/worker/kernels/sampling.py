@@ -1,0 +1,23 @@
+"""Greedy sampling. Reference: swiftllm/worker/layers/post_layer.py:40 (`torch.argmax(logits, dim=1)`)."""
+import torch
+
+from swiftllm_amd import _hip
+
+_scratch = {}   # device -> persistent candidate buffer (fixed address: hipGraph replays use it)
+
+
+def argmax_rows(logits: torch.Tensor) -> torch.Tensor:
+    """[rows, n] fp16/bf16 -> int64 [rows]; ties go to the lowest index (what torch.argmax does too)."""
+    rows, n = logits.shape
+    if n % 8 or logits.stride(1) != 1 or logits.stride(0) % 8 or rows > 65535 or \
+            logits.dtype not in (torch.float16, torch.bfloat16):
+        return torch.argmax(logits, dim=1)      # odd vocabularies: the generic device reduce
+    need = _hip.load().swl_argmax_scratch_bytes(rows)
+    buf = _scratch.get(logits.device)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(max(need, 512 * 64 * 8), dtype=torch.uint8, device=logits.device)
+        _scratch[logits.device] = buf
+    out = torch.empty((rows,), dtype=torch.int64, device=logits.device)
+    _hip.call("swl_argmax", _hip.ptr(out), _hip.ptr(logits), _hip.ptr(buf), buf.numel(), rows, n,
+              logits.stride(0), _hip.dtype_code(logits.dtype), _hip.stream())
+    return out

@@ -3,6 +3,7 @@ import torch
 
 from ..kernels.rmsnorm import rmsnorm_inplace
 from ..kernels.linear import linear
+from ..kernels.sampling import argmax_rows
 
 
 class LlamaPostLayer:
@@ -28,4 +29,4 @@ class LlamaPostLayer:
         logits = linear(last_input, self.weights.lm_head, self.skinny)   # [batch, vocab]
         if self.logits_tap is not None:
             self.logits_tap.append(logits)
-        return torch.argmax(logits, dim=1)
+        return argmax_rows(logits)

@@ -61,6 +61,9 @@ def test_argument_validation_without_a_gpu():
     # empty batches are legal and launch nothing
     assert lib.swl_rmsnorm(None, None, 1e-5, 0, 4096, _hip.SWL_F16, None) == 0
     assert lib.swl_silu_mul(None, 0, 14336, _hip.SWL_F16, None) == 0
+    assert lib.swl_argmax(None, None, None, 0, 0, 128256, 128256, _hip.SWL_BF16, None) == 0
+    assert lib.swl_argmax(None, None, None, 0, 4, 128257, 128264, _hip.SWL_BF16, None) == -1   # n % 8 != 0
+    assert lib.swl_argmax_scratch_bytes(32) == 32 * 64 * 8
     assert lib.swl_swap_blocks(None, None, 0, 1, None, None, None, None, 1 << 20, None) == 0
     # null pointers / bad shapes
     assert lib.swl_rmsnorm(None, None, 1e-5, 4, 4096, _hip.SWL_F16, None) == -1

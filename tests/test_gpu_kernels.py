@@ -581,3 +581,24 @@ def test_gemm_silu_gate_fusion_equals_two_ops(dtype, M, I, Kd):
     # three chained roundings (up, silu(gate), product) on projections that may each be 1 ulp off
     eps = 2.0 ** -7 if dtype == torch.float16 else 2.0 ** -4
     assert ((fused.cpu().float() - ref[:, :I].float()).abs() <= eps * ref[:, :I].float().abs() + 2e-3).all()
+
+
+# ---- greedy sampling -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,n", [(1, 8), (3, 512), (32, 128256), (7, 32000), (5, 1000)])
+def test_argmax_rows_matches_torch_with_lowest_index_ties(dtype, rows, n):
+    from swiftllm_amd.worker.kernels.sampling import argmax_rows
+    g = gen(rows * 31 + n)
+    x = torch.randn(rows, n, generator=g).to(dtype)
+    # plant exact ties for the maximum, far apart (different splits, waves and lanes)
+    for r in range(rows):
+        top = x[r].max() + 1
+        for j in {(r * 37) % n, n - 1 - (r * 11) % n, n // 2}:
+            x[r, j] = top
+    want = torch.tensor([int((x[r] == x[r].max()).nonzero()[0]) for r in range(rows)])
+    got = argmax_rows(x.cuda())
+    assert got.dtype == torch.int64 and torch.equal(got.cpu(), want)
+    wide = torch.randn(rows, n + 64, generator=g).to(dtype).cuda()          # strided rows (a column slice)
+    assert torch.equal(argmax_rows(wide[:, :n]), torch.argmax(wide[:, :n].float(), dim=1))
+    neg = torch.full((2, 64), float("-inf"), dtype=dtype).cuda()
+    assert argmax_rows(neg).tolist() == [0, 0]

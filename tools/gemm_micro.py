@@ -46,6 +46,8 @@ def main():
         res["blas_us"] = round(t, 2); res["blas_TBps"] = round(N * K * 2 / t / 1e6, 2)
         wsp = torch.empty(16 * a.m * N, dtype=torch.float32, device="cuda")
         for ks in (0, 1, 2, 4, 8, 16):
+            if a.m > 32:
+                break
             if ks and (K % (128 * ks) or (ks > 1 and N > 32768)):
                 continue
             def run(i, ks=ks):

@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--no-fuse-qkv", dest="fuse_qkv", action="store_false")
     ap.add_argument("--no-skinny-gemm", dest="skinny_gemm", action="store_false")
     ap.add_argument("--no-splitk-fusion", dest="splitk_fusion", action="store_false")
+    ap.add_argument("--layer-fusion", dest="layer_fusion", action="store_true",
+                    help="fold norm/rotary/residual hand-offs into the GEMMs (experimental, slower: DESIGN.md §4.4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-iters", type=int, default=256)
     return ap.parse_args()
@@ -95,7 +97,8 @@ def build_model(args, cfg, num_blocks):
                       max_blocks_per_seq=max(256, (args.prompt_len + args.steps + args.warmup) // 16 + 8),
                       max_batch_size=args.batch, max_tokens_in_batch=args.batch * args.prompt_len,
                       dtype=args.dtype, fuse_qkv=args.fuse_qkv, use_hip_graph=not args.no_hip_graph,
-                      use_skinny_gemm=args.skinny_gemm, fuse_splitk_consumers=args.splitk_fusion)
+                      use_skinny_gemm=args.skinny_gemm, fuse_splitk_consumers=args.splitk_fusion,
+                      fuse_decode_layer=getattr(args, "layer_fusion", False))
     model = LlamaModel(ec)
     model.load_weights()
     # random-init weights of the named architecture: N(0, 0.02^2) matrices, norm weights 1 + N(0, 0.02^2)

@@ -224,6 +224,37 @@ int swl_gemm_skinny_silu_gate(void *out, const void *x, const void *w_up_gate, i
                               int32_t K, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype,
                               swl_stream_t stream);
 
+/* ---- Fused decode layer: the latency-bound hand-offs between the projections folded into the GEMMs --------
+ * (reference: transformer_layer.py:31-130 runs fused_add_rmsnorm / rotary / store_kvcache as separate
+ * kernels between the linears). Split-K workgroups that share an output tile count themselves in; the last one
+ * to arrive sums the tile's slabs in slab order and applies the consumer. `counters` is int64[counters_len >=
+ * N/128], zero before the first launch (every launch leaves it zero again). M <= 32, N % 128 == 0, K % 128 == 0.
+ *
+ * swl_gemm_skinny_add_residual: residual[M, N] += round(x . W^T); ssq_out[N/128][32] <- per-128-column-tile
+ *   sums of squares of the updated residual rows   (o_proj / down_proj + the add half of rmsnorm.py:39-65)
+ * swl_gemm_skinny_norm_silu_gate: out[M, I] = up * silu(gate) of rmsnorm(x) . [up ; gate]^T, where x is the
+ *   un-normalised residual stream, ssq_in[ssq_parts][32] its per-tile row sums of squares, K <= 4096
+ * swl_gemm_skinny_qkv_rope_store: fused qkv projection (+ attention RMSNorm on the fly when ssq_in != NULL)
+ *   whose epilogue rotates q/k (rotary_emb.py:7-42), writes q_out[M, H, D] and stores k/v into the paged
+ *   pools (kvcache_mgmt.py:50-79). head_dim in {32, 64, 128}. */
+int swl_gemm_skinny_add_residual(void *residual, float *ssq_out, const void *x, const void *w, float *slabs,
+                                 size_t slabs_bytes, int64_t *counters, int32_t counters_len, int32_t M,
+                                 int32_t N, int32_t K, int64_t x_row_stride, int32_t dtype, swl_stream_t stream);
+int swl_gemm_skinny_norm_silu_gate(void *out, const void *x, const float *ssq_in, int32_t ssq_parts,
+                                   const void *norm_w, float eps, const void *w_up_gate, int32_t M, int32_t I,
+                                   int32_t K, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype,
+                                   swl_stream_t stream);
+int swl_gemm_skinny_qkv_rope_store(void *q_out, const void *x, const float *ssq_in, int32_t ssq_parts,
+                                   const void *norm_w, float eps, const void *w_qkv, float *slabs,
+                                   size_t slabs_bytes, int64_t *counters, int32_t counters_len,
+                                   const void *cos_table, const void *sin_table, const int32_t *pos_idx,
+                                   void *k_cache, void *v_cache, const int32_t *block_table,
+                                   const int32_t *seq_ids, const int32_t *seq_lens, int32_t num_decoding_seqs,
+                                   int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, int32_t K,
+                                   int32_t cur_layer, int32_t num_layers, int32_t block_size,
+                                   int32_t max_blocks_per_seq, int64_t q_tok_stride, int64_t x_row_stride,
+                                   int32_t dtype, swl_stream_t stream);
+
 /* Split-K without the reduce launch: the GEMM stops at its fp32 partial slabs [k_splits][M][N] and a FUSED
  * CONSUMER adds them (slab order, one rounding — bit-identical to swl_gemm_skinny's own reduce):
  *   o_proj / down_proj  -> swl_splitk_fused_add_rmsnorm      (reference: rmsnorm.py:39-89)

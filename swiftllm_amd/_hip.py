@@ -57,6 +57,11 @@ SIGNATURES = {
     "swl_gemm_skinny_partial": [_P, ctypes.c_size_t, _P, _P, _I32, _I32, _I32, _I64, _I32, _I32, _P],
     "swl_splitk_reduce": [_P, _P, _I32, _I32, _I32, _I64, _I32, _P],
     "swl_gemm_skinny_silu_gate": [_P, _P, _P, _I32, _I32, _I32, _I64, _I64, _I32, _P],
+    "swl_gemm_skinny_add_residual": [_P, _P, _P, _P, _P, ctypes.c_size_t, _P, _I32, _I32, _I32, _I32, _I64, _I32, _P],
+    "swl_gemm_skinny_norm_silu_gate": [_P, _P, _P, _I32, _P, _F32, _P, _I32, _I32, _I32, _I64, _I64, _I32, _P],
+    "swl_gemm_skinny_qkv_rope_store": [_P, _P, _P, _I32, _P, _F32, _P, _P, ctypes.c_size_t, _P, _I32, _P, _P, _P,
+                                       _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32,
+                                       _I64, _I64, _I32, _P],
     "swl_splitk_fused_add_rmsnorm": [_P, _P, _P, _F32, _P, _I32, _I64, _I32, _I32, _P],
     "swl_splitk_rotary_store_kv_decode": [_P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32,
                                           _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _P],

@@ -12,17 +12,6 @@
 
 namespace swl {
 
-template <typename T>
-__device__ __forceinline__ void rotate8(vec8_t<T> &x0, vec8_t<T> &x1, const vec8_t<T> &c,
-                                        const vec8_t<T> &s) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const T a = x0[j], b = x1[j];
-        x0[j] = sub_t<T>(mul_t<T>(a, c[j]), mul_t<T>(b, s[j]));
-        x1[j] = add_t<T>(mul_t<T>(a, s[j]), mul_t<T>(b, c[j]));
-    }
-}
-
 // Work item = (token, head in [0, H+KVH), chunk in [0, D/16)).
 template <typename T>
 __global__ __launch_bounds__(256) void rotary_kernel(T *__restrict__ q, T *__restrict__ k,

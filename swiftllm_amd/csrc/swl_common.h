@@ -135,9 +135,82 @@ __device__ __forceinline__ float wave_allreduce_max(float v) {
 // Split-K consumers: 8 consecutive outputs of a skinny-GEMM whose K was split across workgroups into `ks`
 // fp32 partial slabs (slab k at slabs + k*slab_stride); summed in slab order, rounded once to T — exactly
 // what the stand-alone reduce kernel of gemm_skinny.hip produces.
+// Device-coherent 16-byte accesses (relaxed atomics at agent scope = sc1 loads/stores on gfx950): the store
+// is written through to the level all XCDs share and the load never trusts a line of the local L2, so data
+// can be handed from one workgroup to another INSIDE a kernel without whole-cache writeback/invalidate
+// fences (a __threadfence() per workgroup costs a full L2 writeback: measured 4.6 -> 7.7 ms per decode step).
+__device__ __forceinline__ void store_f4_coherent(float *p, const float4_t &v) {
+    typedef unsigned long long u64;
+    union { float f[4]; u64 u[2]; } b;
+    b.f[0] = v[0]; b.f[1] = v[1]; b.f[2] = v[2]; b.f[3] = v[3];
+    __hip_atomic_store(reinterpret_cast<u64 *>(p), b.u[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<u64 *>(p) + 1, b.u[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4_t load_f4_coherent(const float *p) {
+    typedef unsigned long long u64;
+    union { float f[4]; u64 u[2]; } b;
+    b.u[0] = __hip_atomic_load(reinterpret_cast<const u64 *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    b.u[1] = __hip_atomic_load(reinterpret_cast<const u64 *>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return float4_t{b.f[0], b.f[1], b.f[2], b.f[3]};
+}
+
+// KS known at compile time: all KS loads are issued before the first add (one memory round trip instead
+// of a load -> add chain per slab); the adds keep the slab order, so the bits do not depend on KS being
+// static or not.
+template <typename T, int KS, bool COHERENT = false>
+__device__ __forceinline__ vec8_t<T> load8_splitk_static(const float *slabs, int64_t slab_stride,
+                                                         int64_t elem_off) {
+    float4_t a[KS], b[KS];
+    const float *p = slabs + elem_off;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+        if constexpr (COHERENT) {
+            a[k] = load_f4_coherent(p + k * slab_stride);
+            b[k] = load_f4_coherent(p + k * slab_stride + 4);
+        } else {
+            a[k] = *reinterpret_cast<const float4_t *>(p + k * slab_stride);
+            b[k] = *reinterpret_cast<const float4_t *>(p + k * slab_stride + 4);
+        }
+    }
+    float4_t sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+        sa += a[k];
+        sb += b[k];
+    }
+    vec8_t<T> r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        r[e] = static_cast<T>(sa[e]);
+        r[4 + e] = static_cast<T>(sb[e]);
+    }
+    return r;
+}
+
+// Slabs written by other workgroups of the SAME kernel (split-K completion in gemm_skinny.hip).
+template <typename T>
+__device__ __forceinline__ vec8_t<T> load8_splitk_coherent(const float *slabs, int ks, int64_t slab_stride,
+                                                           int64_t elem_off) {
+    switch (ks) {
+    case 1: return load8_splitk_static<T, 1, true>(slabs, slab_stride, elem_off);
+    case 2: return load8_splitk_static<T, 2, true>(slabs, slab_stride, elem_off);
+    case 4: return load8_splitk_static<T, 4, true>(slabs, slab_stride, elem_off);
+    case 8: return load8_splitk_static<T, 8, true>(slabs, slab_stride, elem_off);
+    default: return load8_splitk_static<T, 16, true>(slabs, slab_stride, elem_off);
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ vec8_t<T> load8_splitk(const float *slabs, int ks, int64_t slab_stride,
                                                   int64_t elem_off) {
+    switch (ks) { // uniform branch; the k-split counts the skinny GEMM actually uses
+    case 1: return load8_splitk_static<T, 1>(slabs, slab_stride, elem_off);
+    case 2: return load8_splitk_static<T, 2>(slabs, slab_stride, elem_off);
+    case 4: return load8_splitk_static<T, 4>(slabs, slab_stride, elem_off);
+    case 8: return load8_splitk_static<T, 8>(slabs, slab_stride, elem_off);
+    case 16: return load8_splitk_static<T, 16>(slabs, slab_stride, elem_off);
+    default: break;
+    }
     float4_t a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
     const float *p = slabs + elem_off;
     for (int k = 0; k < ks; ++k, p += slab_stride) {
@@ -151,6 +224,19 @@ __device__ __forceinline__ vec8_t<T> load8_splitk(const float *slabs, int ks, in
         r[4 + e] = static_cast<T>(b[e]);
     }
     return r;
+}
+
+// Rotate-half rotary embedding on 8 (first-half, second-half) pairs. Rounding points follow the
+// reference (rotary_emb.py:34-42): every product and every sum is rounded to the storage dtype.
+template <typename T>
+__device__ __forceinline__ void rotate8(vec8_t<T> &x0, vec8_t<T> &x1, const vec8_t<T> &c,
+                                        const vec8_t<T> &s) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const T a = x0[j], b = x1[j];
+        x0[j] = sub_t<T>(mul_t<T>(a, c[j]), mul_t<T>(b, s[j]));
+        x1[j] = add_t<T>(mul_t<T>(a, s[j]), mul_t<T>(b, c[j]));
+    }
 }
 
 // exp2 on the hardware transcendental unit (v_exp_f32 IS 2^x).

@@ -12,11 +12,18 @@ Decode fast path (use_skinny_gemm): projections whose K is split across workgrou
 partial slabs (SplitKPartials) straight to the next kernel — fused qkv -> rotary+KV-store,
 o_proj -> the FFN's fused_add_rmsnorm, down_proj -> the NEXT layer's fused_add_rmsnorm — so `forward`
 may return, and accept, a SplitKPartials in place of the activation tensor.
+
+Fused decode layer (fuse_decode_layer, batches of <= 32 sequences): the hand-offs themselves move into the
+GEMMs — qkv projection (+ attention norm on the fly) with rotary/KV-store in its epilogue, attention,
+o_proj with the residual add in its epilogue, up/gate (+ FFN norm on the fly) with SiLU-gate, down_proj with
+the residual add: 5 launches per layer instead of 8. The layer then returns a NormPending (the residual
+stream already holds the sum; its RMSNorm is applied by whoever consumes it).
 """
 import torch
 
-from ..kernels.linear import SplitKPartials, linear, linear_silu_gate, linear_splitk
-from ..kernels.rmsnorm import fused_add_rmsnorm_inplace, fused_add_rmsnorm_from_splitk
+from ..kernels.linear import (NormPending, SplitKPartials, fused_layer_ok, linear, linear_add_residual,
+                              linear_norm_silu_gate, linear_qkv_rope_store, linear_silu_gate, linear_splitk)
+from ..kernels.rmsnorm import fused_add_rmsnorm_inplace, fused_add_rmsnorm_from_splitk, rmsnorm_inplace
 from ..kernels.rotary_emb import (rotary_embedding_inplace, rotary_embedding_and_store_kvcache_decode,
                                   rotary_embedding_and_store_kvcache_decode_from_splitk)
 from ..kernels.kvcache_mgmt import store_kvcache
@@ -55,12 +62,53 @@ class LlamaTransformerLayer:
                 v_cache: torch.Tensor, block_table: torch.Tensor, infer_state):
         cfg, ecfg, w, st = self.model_config, self.engine_config, self.weight, infer_state
 
+        if self._fused_decode_applies(st, residual_buf):
+            return self._forward_decode_fused(input_embds, residual_buf, k_cache, v_cache, block_table, st)
+        if isinstance(input_embds, NormPending):    # (a fused layer followed by an unfused one: same stream)
+            input_embds = self._materialize_norm(input_embds, w.attn_norm)
+            return self._forward_after_attn_norm(input_embds, residual_buf, k_cache, v_cache, block_table, st)
+
         # residual_buf <- input_embds + residual_buf ; input_embds <- rmsnorm(residual_buf)
         if isinstance(input_embds, SplitKPartials):     # the previous layer's down projection, unreduced
             input_embds = fused_add_rmsnorm_from_splitk(input_embds, residual_buf, w.attn_norm,
                                                         cfg.rms_norm_eps)
         else:
             fused_add_rmsnorm_inplace(input_embds, residual_buf, w.attn_norm, cfg.rms_norm_eps)
+        return self._forward_after_attn_norm(input_embds, residual_buf, k_cache, v_cache, block_table, st)
+
+    def _fused_decode_applies(self, st, residual_buf) -> bool:
+        cfg, ecfg, w = self.model_config, self.engine_config, self.weight
+        return (self.skinny and getattr(ecfg, "fuse_decode_layer", False) and w.qkv_proj is not None
+                and st.num_prefill_seqs == 0 and st.num_decoding_seqs > 0 and not st.ignore_kvcache
+                and st.position_indices is not None and residual_buf.is_contiguous()
+                and fused_layer_ok(st.num_decoding_seqs, cfg.hidden_size, cfg.num_q_heads, cfg.num_kv_heads,
+                                   cfg.head_dim, cfg.ffn_inter_dim))
+
+    def _materialize_norm(self, pending: NormPending, norm_w: torch.Tensor) -> torch.Tensor:
+        x = pending.residual.clone()
+        rmsnorm_inplace(x, norm_w, self.model_config.rms_norm_eps)
+        return x
+
+    def _forward_decode_fused(self, input_embds, residual_buf, k_cache, v_cache, block_table, st):
+        cfg, ecfg, w = self.model_config, self.engine_config, self.weight
+        eps = cfg.rms_norm_eps
+        if not isinstance(input_embds, NormPending):
+            # first layer (or after an unfused one): the ordinary add + norm, then the projection as it is
+            if isinstance(input_embds, SplitKPartials):
+                input_embds = fused_add_rmsnorm_from_splitk(input_embds, residual_buf, w.attn_norm, eps)
+            else:
+                fused_add_rmsnorm_inplace(input_embds, residual_buf, w.attn_norm, eps)
+        q = linear_qkv_rope_store(input_embds, w.attn_norm, eps, w.qkv_proj, k_cache, v_cache, block_table, cfg,
+                                  ecfg, st, self.layer_id)
+        o = torch.empty_like(residual_buf)
+        paged_attention(q, k_cache, v_cache, block_table, cfg, ecfg, st, self.layer_id,
+                        o.view(-1, cfg.num_q_heads, cfg.head_dim))
+        stream = linear_add_residual(o, w.o_proj, residual_buf)
+        act = linear_norm_silu_gate(stream, w.ffn_norm, eps, w.up_gate_proj)
+        return linear_add_residual(act, w.down_proj, residual_buf)
+
+    def _forward_after_attn_norm(self, input_embds, residual_buf, k_cache, v_cache, block_table, infer_state):
+        cfg, ecfg, w, st = self.model_config, self.engine_config, self.weight, infer_state
 
         pure_decode = st.num_prefill_seqs == 0 and st.num_decoding_seqs > 0
         fused_rope_store = (pure_decode and not st.ignore_kvcache and st.position_indices is not None

@@ -34,6 +34,7 @@ from .batch_plan import BatchPlan, plan_batch
 from .block_manager import BlockManager
 from .infer_state import LlamaInferState
 from .kernels.block_swapping import swap_blocks
+from .kernels.linear import NormPending
 from .layers.pre_layer import LlamaPreLayer
 from .layers.transformer_layer import LlamaTransformerLayer
 from .layers.post_layer import LlamaPostLayer
@@ -237,6 +238,8 @@ class LlamaModel:
         block_table = None if infer_state.ignore_kvcache else self.gpu_block_manager.block_table
         for layer in self.transformer_layers:
             x = layer.forward(x, residual, self.k_cache, self.v_cache, block_table, infer_state)
+        if isinstance(x, NormPending):          # fused decode layers: the stream already holds x + residual
+            return self.post_layer.forward(x.residual, infer_state)
         if not isinstance(x, torch.Tensor):     # the last down projection left as split-K partials
             x = x.materialize()
         x += residual

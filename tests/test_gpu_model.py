@@ -32,9 +32,10 @@ def _make_model(tmp_path, cfg, sd, num_blocks=24, **kw):
 
 @pytest.mark.parametrize("opts", [dict(), dict(fuse_qkv=False, use_skinny_gemm=False),
                                   dict(fuse_qkv=False), dict(use_skinny_gemm=False),
-                                  dict(fuse_rope_kvstore=False), dict(use_hip_graph=True)],
+                                  dict(fuse_rope_kvstore=False), dict(use_hip_graph=True),
+                                  dict(fuse_decode_layer=True), dict(fuse_decode_layer=True, use_hip_graph=True)],
                          ids=["default", "reference_blas_calls", "unfused_qkv", "blas_gemm", "unfused_rope",
-                              "hipgraph"])
+                              "hipgraph", "fused_layer", "fused_layer_hipgraph"])
 def test_forward_matches_reference_golden(tmp_path, golden, opts):
     """The scripted run frozen from the reference (fp16, BASELINE configs[0] model)."""
     g = golden("e2e_tiny_fp16.pt")
@@ -63,14 +64,15 @@ def _run_script(model, prompts, decode_steps, seq_ids=None):
 
 @pytest.mark.parametrize("shape", ["TINY", "SMALL64", "SMALL128"])
 @pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
-def test_forward_matches_oracle_model(tmp_path, shape, dtype):
+@pytest.mark.parametrize("fused_layer", [False, True], ids=["per_op", "fused_layer"])
+def test_forward_matches_oracle_model(tmp_path, shape, dtype, fused_layer):
     """head_dim 32 / 64 / 128 (all kernel specialisations), prompts crossing block and tile
     boundaries, 20 decode steps, both dtypes: identical greedy tokens, close logits."""
     cfg = synth.make_config(**getattr(synth, shape))
     tdtype = torch.float16 if dtype == "float16" else torch.bfloat16
     sd = synth.make_state_dict(cfg, seed=5, dtype=tdtype)
     from swiftllm_amd import LlamaModelConfig
-    ecfg = dict(max_blocks_per_seq=32, max_tokens_in_batch=1024, dtype=dtype)
+    ecfg = dict(max_blocks_per_seq=32, max_tokens_in_batch=1024, dtype=dtype, fuse_decode_layer=fused_layer)
     model = _make_model(tmp_path, cfg, sd, 64, **ecfg)
     ref = RefLlamaModel(LlamaModelConfig(cfg), _engine_config("", **ecfg), sd, tdtype)
     ref.init_kvcache_and_swap(64)

@@ -102,6 +102,20 @@ int swl_store_kv_decode(void *k_cache, void *v_cache, const void *k, const void 
 int swl_silu_mul(void *x, int64_t num_tokens, int32_t ffn_inter_dim, int32_t dtype,
                  swl_stream_t stream);
 
+/* Decode attention fed directly by the split-K slabs of the fused qkv projection (swl_gemm_skinny_partial,
+ * k_splits >= 1): the rotary embedding and the KV-cache store of the new token (reference rotary_emb.py:7-42 +
+ * kvcache_mgmt.py:50-79, separate launches at transformer_layer.py:62-77) run in the attention kernel's
+ * prologue; results are bit-identical to swl_splitk_rotary_store_kv_decode + swl_paged_attn_decode.
+ * qkv_slabs: [k_splits][Bd][(H + 2*KVH) * D] fp32. Other arguments as swl_paged_attn_decode. */
+int swl_paged_attn_decode_qkv(void *o, const float *qkv_slabs, int32_t k_splits, const void *cos_table,
+                              const void *sin_table, const int32_t *pos_idx, void *k_cache, void *v_cache,
+                              const int32_t *block_table, const int32_t *seq_ids, const int32_t *seq_lens,
+                              void *scratch, float softmax_scale, int32_t num_decoding_seqs,
+                              int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, int32_t num_layers,
+                              int32_t block_size, int32_t cur_layer, int32_t max_blocks_per_seq,
+                              int32_t seq_block_size, int32_t num_seq_blocks, int64_t o_tok_stride,
+                              int32_t dtype, swl_stream_t stream);
+
 /* ---- Greedy sampling --------------------------------------------------------------------------
  * reference: post_layer.py:40 (`torch.argmax(logits, dim=1)`)
  * out[r] = argmax_j x[r, j] (int64), ties -> lowest j, NaNs never selected. n % 8 == 0.

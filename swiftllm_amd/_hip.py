@@ -43,6 +43,8 @@ SIGNATURES = {
                               _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I32, _P],
     "swl_paged_attn_phase1": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F32, _I32, _I32, _I32, _I32,
                               _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I32, _P],
+    "swl_paged_attn_decode_qkv": [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F32, _I32, _I32, _I32, _I32,
+                                  _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I32, _P],
     "swl_paged_attn_phase2": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I64, _I32, _P],
     "swl_prefill_attn_varlen": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F32, _I64, _I64,
                                 _I64, _I64, _I32, _P],

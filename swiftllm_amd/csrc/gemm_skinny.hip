@@ -575,7 +575,7 @@ static int run_gemm(T *out, const T *x, const T *w, float *ws, size_t ws_bytes, 
     const dim3 grid((tiles + kGemmWaves - 1) / kGemmWaves, ks);
     const int kc = K / ks;
     const bool ring = use_ring(kc);
-    if (ks == 1) {
+    if (ks == 1 && reduce) {
         if (ring)
             hipLaunchKernelGGL((gemm_skinny_ring_kernel<T, kGemmDirect>), grid, dim3(kGemmWaves * 64), 0, stream,
                                out, x, w, M, N, K, kc, xs, os, GemmFuse{});
@@ -640,7 +640,7 @@ extern "C" int swl_gemm_skinny_partial(float *slabs, size_t slabs_bytes, const v
                                        int32_t k_splits, int32_t dtype, swl_stream_t stream) {
     if (M < 0 || N <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
     if (M == 0) return SWL_OK;
-    if (!slabs || !x || !w || k_splits < 2 || k_splits > 16 || (k_splits & (k_splits - 1)))
+    if (!slabs || !x || !w || k_splits < 1 || k_splits > 16 || (k_splits & (k_splits - 1)))
         return SWL_ERR_BAD_ARG;
     if (M > 32 || (N & 31) || (K & (swl::kKT - 1))) return SWL_ERR_UNSUPPORTED;
     if (x_row_stride < K || (x_row_stride & 7) || !swl::aligned16(x) || !swl::aligned16(w) ||

@@ -46,6 +46,11 @@ struct PagedAttnParams {
     float scale_log2e;
     int H, KVH, L, layer, max_blocks_per_seq, seq_block_size, num_seq_blocks;
     int64_t q_tok_stride, o_tok_stride;
+    // QKV variant: q/k/v of the new token are still the split-K partial slabs of the fused qkv projection
+    const float *qkv_slabs; // [ks][Bd][(H + 2*KVH) * D] fp32
+    int ks;
+    const void *cos_t, *sin_t; // rope tables [positions][D/2]
+    const int *pos_idx;        // table row per sequence (NULL: seq_len - 1)
 };
 
 template <typename T, int D, int G>
@@ -113,13 +118,21 @@ __device__ __forceinline__ void attend_block(const vec8_t<T> (&qv)[G],
 // NW = waves per workgroup: 4 for short sequence blocks (latency-bound launches that want many
 // small workgroups), 8 for long ones (one workgroup per CU, every wave streams many KV blocks and the
 // per-workgroup prologue/merge is amortised; 8 waves x 16 KiB of K/V in flight per CU).
-template <typename T, int D, int G, int NW>
+//
+// QKV = true: the rotary + KV-store step of the layer (rotary_emb.py + kvcache_mgmt.py:50-79) runs in this
+// kernel's prologue instead of a launch of its own. The workgroup sums the fused-qkv slabs of its G query
+// heads and its kv head, rotates q and k (same arithmetic and rounding as rotary.hip), keeps the rounded q in
+// LDS for its waves, and — in the split that owns the last position — writes the new k/v into the pool and
+// patches them into the registers of the wave that attends that block (the pool read raced with the write).
+template <typename T, int D, int G, int NW, bool QKV = false>
 __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnParams p) {
     using Tile = DecodeTile<T, D, G>;
     constexpr int LPT = Tile::LPT, TPI = Tile::TPI, NI = Tile::NI;
     constexpr int NT = NW * 64;
     __shared__ float sm_ml[NW][G][2];
     __shared__ float sm_acc[NW][G][D];
+    __shared__ __attribute__((aligned(16))) T sm_q[QKV ? G * D : 8];
+    __shared__ __attribute__((aligned(16))) T sm_kv[QKV ? 2 * D : 8];
 
     const int split = blockIdx.x;
     const int kvh = blockIdx.y;
@@ -145,12 +158,14 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
     const int64_t blk_pitch = static_cast<int64_t>(p.L) * p.KVH;
 
     vec8_t<T> qv[G];
-    {
+    if constexpr (!QKV) {
         const T *qp = static_cast<const T *>(p.q) + seq * p.q_tok_stride +
                       static_cast<int64_t>(kvh) * G * D + chunk * 8;
 #pragma unroll
         for (int g = 0; g < G; ++g) qv[g] = load8(qp + g * D);
     }
+    const int pos = len - 1;          // the token being decoded
+    const int last_blk = pos / kBlk;
 
     float m[G], l[G], acc[G][8];
 #pragma unroll
@@ -171,8 +186,18 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
             Vr[i] = load8_nt(vc + base + i * 512);
         }
     };
-    auto attend = [&](int b, const vec8_t<T>(&Kr)[NI], const vec8_t<T>(&Vr)[NI]) {
+    auto attend = [&](int b, vec8_t<T>(&Kr)[NI], vec8_t<T>(&Vr)[NI]) {
         const int tok0 = b * kBlk;
+        if constexpr (QKV) {
+            if (b == last_blk) { // the new token's slot: take k/v from the prologue, not from the pool
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    if (tok0 + i * TPI + row == pos) {
+                        Kr[i] = *reinterpret_cast<const vec8_t<T> *>(&sm_kv[chunk * 8]);
+                        Vr[i] = *reinterpret_cast<const vec8_t<T> *>(&sm_kv[D + chunk * 8]);
+                    }
+            }
+        }
         if (tok0 + kBlk > len)
             attend_block<T, D, G, true>(qv, Kr, Vr, m, l, acc, c, tok0, row, len);
         else
@@ -180,8 +205,51 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
     };
 
     int b = tok_begin / kBlk + wave;
+    if (b < blk_end) load_block(b, Ka, Va); // first: the KV stream starts while the prologue below runs
+    if constexpr (QKV) {
+        const bool owner = tok_end == len; // the split that attends (and stores) the new token
+        constexpr int kRot = D / 16;         // rotation items per head
+        const int n_items = G * kRot + (owner ? kRot + D / 8 : 0);
+        const int64_t qkv_row = static_cast<int64_t>(p.H + 2 * p.KVH) * D;
+        const int64_t slab_stride = static_cast<int64_t>(gridDim.z) * qkv_row;
+        const int64_t row_off = seq * qkv_row;
+        const int64_t trow = p.pos_idx ? p.pos_idx[seq] : pos;
+        for (int item = threadIdx.x; item < n_items; item += NT) {
+            if (item < (G + 1) * kRot) {
+                const bool is_q = item < G * kRot;
+                const int c = item % kRot;
+                const int head = is_q ? kvh * G + item / kRot : p.H + kvh;
+                const vec8_t<T> cv = load8(static_cast<const T *>(p.cos_t) + trow * (D / 2) + c * 8);
+                const vec8_t<T> sv = load8(static_cast<const T *>(p.sin_t) + trow * (D / 2) + c * 8);
+                const int64_t off = row_off + static_cast<int64_t>(head) * D + c * 8;
+                vec8_t<T> x0 = load8_splitk<T>(p.qkv_slabs, p.ks, slab_stride, off);
+                vec8_t<T> x1 = load8_splitk<T>(p.qkv_slabs, p.ks, slab_stride, off + D / 2);
+                rotate8<T>(x0, x1, cv, sv);
+                T *dst = is_q ? &sm_q[(item / kRot) * D] : &sm_kv[0];
+                *reinterpret_cast<vec8_t<T> *>(dst + c * 8) = x0;
+                *reinterpret_cast<vec8_t<T> *>(dst + D / 2 + c * 8) = x1;
+                if (!is_q) {
+                    T *pool = const_cast<T *>(kc) + (static_cast<int64_t>(bt[last_blk]) * blk_pitch + layer_head) *
+                                                        tile_elems + (pos % kBlk) * D;
+                    store8(pool + c * 8, x0);
+                    store8(pool + D / 2 + c * 8, x1);
+                }
+            } else {
+                const int c = item - (G + 1) * kRot;
+                const vec8_t<T> vv = load8_splitk<T>(
+                    p.qkv_slabs, p.ks, slab_stride,
+                    row_off + static_cast<int64_t>(p.H + p.KVH + kvh) * D + c * 8);
+                *reinterpret_cast<vec8_t<T> *>(&sm_kv[D + c * 8]) = vv;
+                T *pool = const_cast<T *>(vc) + (static_cast<int64_t>(bt[last_blk]) * blk_pitch + layer_head) *
+                                                    tile_elems + (pos % kBlk) * D;
+                store8(pool + c * 8, vv);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < G; ++g) qv[g] = *reinterpret_cast<const vec8_t<T> *>(&sm_q[g * D + chunk * 8]);
+    }
     if (b < blk_end) {
-        load_block(b, Ka, Va);
         while (true) {
             if (b + NW < blk_end) load_block(b + NW, Kb, Vb);
             attend(b, Ka, Va);
@@ -292,35 +360,35 @@ __global__ __launch_bounds__(64) void paged_attn_phase2_kernel(
     }
 }
 
-template <typename T, int D, int G>
+template <typename T, int D, int G, bool QKV>
 static int launch_phase1(const PagedAttnParams &p, int Bd, hipStream_t stream) {
     const dim3 grid(p.num_seq_blocks, p.KVH, Bd);
     // >= 32 KV blocks per sequence block: 8-wave workgroups (>= 4 blocks per wave); else 4 waves.
     // (G = 8 needs > 256 registers per lane: it stays on 4-wave workgroups, one wave per SIMD.)
     if (G <= 4 && p.seq_block_size >= 32 * kBlk)
-        hipLaunchKernelGGL((paged_attn_phase1_kernel<T, D, G, 8>), grid, dim3(512), 0, stream, p);
+        hipLaunchKernelGGL((paged_attn_phase1_kernel<T, D, G, 8, QKV>), grid, dim3(512), 0, stream, p);
     else
-        hipLaunchKernelGGL((paged_attn_phase1_kernel<T, D, G, 4>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((paged_attn_phase1_kernel<T, D, G, 4, QKV>), grid, dim3(256), 0, stream, p);
     return check_launch();
 }
 
-template <typename T, int D>
+template <typename T, int D, bool QKV>
 static int dispatch_phase1_g(const PagedAttnParams &p, int Bd, int G, hipStream_t stream) {
     switch (G) {
-    case 1: return launch_phase1<T, D, 1>(p, Bd, stream);
-    case 2: return launch_phase1<T, D, 2>(p, Bd, stream);
-    case 4: return launch_phase1<T, D, 4>(p, Bd, stream);
-    case 8: return launch_phase1<T, D, 8>(p, Bd, stream);
+    case 1: return launch_phase1<T, D, 1, QKV>(p, Bd, stream);
+    case 2: return launch_phase1<T, D, 2, QKV>(p, Bd, stream);
+    case 4: return launch_phase1<T, D, 4, QKV>(p, Bd, stream);
+    case 8: return launch_phase1<T, D, 8, QKV>(p, Bd, stream);
     default: return SWL_ERR_UNSUPPORTED;
     }
 }
 
-template <typename T>
+template <typename T, bool QKV = false>
 static int dispatch_phase1(const PagedAttnParams &p, int Bd, int D, int G, hipStream_t stream) {
     switch (D) {
-    case 32: return dispatch_phase1_g<T, 32>(p, Bd, G, stream);
-    case 64: return dispatch_phase1_g<T, 64>(p, Bd, G, stream);
-    case 128: return dispatch_phase1_g<T, 128>(p, Bd, G, stream);
+    case 32: return dispatch_phase1_g<T, 32, QKV>(p, Bd, G, stream);
+    case 64: return dispatch_phase1_g<T, 64, QKV>(p, Bd, G, stream);
+    case 128: return dispatch_phase1_g<T, 128, QKV>(p, Bd, G, stream);
     default: return SWL_ERR_UNSUPPORTED;
     }
 }
@@ -375,7 +443,7 @@ extern "C" int swl_paged_attn_phase1(void *o_direct, const void *q, const void *
         (q_tok_stride & 7))
         return SWL_ERR_BAD_ARG;
     if (num_decoding_seqs > 65535 || num_kv_heads > 65535) return SWL_ERR_UNSUPPORTED;
-    swl::PagedAttnParams p;
+    swl::PagedAttnParams p{};
     p.o_direct = o_direct;
     p.q = q;
     p.k_cache = k_cache;
@@ -449,4 +517,68 @@ extern "C" int swl_paged_attn_decode(void *o, const void *q, const void *k_cache
     return swl_paged_attn_phase2(o, mid_o, mid_lse, seq_lens, num_decoding_seqs, num_q_heads,
                                  head_dim, seq_block_size, num_seq_blocks, o_tok_stride, dtype,
                                  stream);
+}
+
+/* Decode attention fed by the split-K slabs of the fused qkv projection: rotary + KV-store of the new token run
+ * in the attention kernel's prologue (no launch of their own), the new k/v are attended from registers. */
+extern "C" int swl_paged_attn_decode_qkv(void *o, const float *qkv_slabs, int32_t k_splits, const void *cos_table,
+                                         const void *sin_table, const int32_t *pos_idx, void *k_cache,
+                                         void *v_cache, const int32_t *block_table, const int32_t *seq_ids,
+                                         const int32_t *seq_lens, void *scratch, float softmax_scale,
+                                         int32_t num_decoding_seqs, int32_t num_q_heads, int32_t num_kv_heads,
+                                         int32_t head_dim, int32_t num_layers, int32_t block_size,
+                                         int32_t cur_layer, int32_t max_blocks_per_seq, int32_t seq_block_size,
+                                         int32_t num_seq_blocks, int64_t o_tok_stride, int32_t dtype,
+                                         swl_stream_t stream) {
+    if (num_decoding_seqs < 0) return SWL_ERR_BAD_ARG;
+    if (num_decoding_seqs == 0 || num_seq_blocks == 0) return SWL_OK;
+    if (!o || !qkv_slabs || !cos_table || !sin_table || !k_cache || !v_cache || !block_table || !seq_ids ||
+        !seq_lens || k_splits <= 0)
+        return SWL_ERR_BAD_ARG;
+    if (num_seq_blocks < 0 || num_q_heads <= 0 || num_kv_heads <= 0 || num_q_heads % num_kv_heads != 0 ||
+        num_layers <= 0 || cur_layer < 0 || cur_layer >= num_layers || max_blocks_per_seq <= 0)
+        return SWL_ERR_BAD_ARG;
+    if (block_size != swl::kBlk) return SWL_ERR_UNSUPPORTED;
+    if (seq_block_size <= 0 || seq_block_size % block_size != 0) return SWL_ERR_BAD_ARG;
+    if (!swl::aligned16(qkv_slabs) || !swl::aligned16(k_cache) || !swl::aligned16(v_cache) ||
+        !swl::aligned16(cos_table) || !swl::aligned16(sin_table))
+        return SWL_ERR_BAD_ARG;
+    if (num_decoding_seqs > 65535 || num_kv_heads > 65535) return SWL_ERR_UNSUPPORTED;
+    float *mid_o = nullptr, *mid_lse = nullptr;
+    if (num_seq_blocks > 1) {
+        if (!scratch || !swl::aligned16(scratch)) return SWL_ERR_BAD_ARG;
+        mid_o = static_cast<float *>(scratch);
+        mid_lse = mid_o + static_cast<size_t>(num_decoding_seqs) * num_q_heads * num_seq_blocks * head_dim;
+    }
+    swl::PagedAttnParams p{};
+    p.o_direct = o;
+    p.k_cache = k_cache;
+    p.v_cache = v_cache;
+    p.block_table = block_table;
+    p.seq_ids = seq_ids;
+    p.seq_lens = seq_lens;
+    p.mid_o = mid_o;
+    p.mid_lse = mid_lse;
+    p.scale_log2e = softmax_scale * 1.44269504088896340736f;
+    p.H = num_q_heads;
+    p.KVH = num_kv_heads;
+    p.L = num_layers;
+    p.layer = cur_layer;
+    p.max_blocks_per_seq = max_blocks_per_seq;
+    p.seq_block_size = seq_block_size;
+    p.num_seq_blocks = num_seq_blocks;
+    p.o_tok_stride = o_tok_stride;
+    p.qkv_slabs = qkv_slabs;
+    p.ks = k_splits;
+    p.cos_t = cos_table;
+    p.sin_t = sin_table;
+    p.pos_idx = pos_idx;
+    const int G = num_q_heads / num_kv_heads;
+    int rc;
+    SWL_DISPATCH_DTYPE(dtype, T, {
+        rc = swl::dispatch_phase1<T, true>(p, num_decoding_seqs, head_dim, G, static_cast<hipStream_t>(stream));
+    });
+    if (rc != SWL_OK || num_seq_blocks == 1) return rc;
+    return swl_paged_attn_phase2(o, mid_o, mid_lse, seq_lens, num_decoding_seqs, num_q_heads, head_dim,
+                                 seq_block_size, num_seq_blocks, o_tok_stride, dtype, stream);
 }

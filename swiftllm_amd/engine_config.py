@@ -46,6 +46,8 @@ class EngineConfig:
     use_skinny_gemm: bool = True
     # On the skinny-GEMM decode path, let the next kernel sum split-K partial slabs (no reduce launches).
     fuse_splitk_consumers: bool = True
+    # Pure-decode batches on the split-K path: rotary + KV store run in the paged-attention kernel's prologue.
+    fuse_rope_into_attention: bool = True
     # Decode batches of <= 32 sequences: fold residual-add / RMSNorm / rotary / KV-store into the projection
     # GEMMs (5 launches per layer instead of 8). Parity-tested but OFF: on MI355X the in-kernel hand-off (slab
     # write-through + device-scope count + last-arriver reduce) costs ~6 us per projection, as much as the

@@ -78,14 +78,15 @@ def linear(a: torch.Tensor, w: torch.Tensor, skinny: bool = False) -> torch.Tens
     return F.linear(a, w)
 
 
-def linear_splitk(a: torch.Tensor, w: torch.Tensor):
+def linear_splitk(a: torch.Tensor, w: torch.Tensor, always: bool = False):
     """Like linear(a, w, skinny=True) but returns SplitKPartials when the kernel splits K (the caller
-    hands them to a fused consumer); falls through to `linear` otherwise."""
+    hands them to a fused consumer); falls through to `linear` otherwise. `always`: also return the
+    partial form (a single fp32 slab) when K is not split — for consumers that only take slabs."""
     if _skinny_ok(a, w):
         m, k = a.shape
         n = w.shape[0]
         ks = _hip.load().swl_gemm_skinny_choose_splits(n, k)
-        if ks > 1:
+        if ks > 1 or (always and ks == 1):
             ws = _workspace(a.device, ks * m * n * 4)
             _hip.call("swl_gemm_skinny_partial", _hip.ptr(ws), ws.numel() * 4, _hip.ptr(a), _hip.ptr(w), m, n, k,
                       _row_stride(a), ks, _hip.dtype_code(a.dtype), _hip.stream())

@@ -40,3 +40,35 @@ def paged_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tenso
               model_config.num_layers, engine_config.block_size, cur_layer, block_table.shape[1],
               infer_state.seq_block_size, nsb, token_stride(q, "q"), token_stride(o, "o"),
               _hip.dtype_code(q.dtype), _hip.stream())
+
+
+def paged_attention_from_qkv_splitk(partials, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                                    block_table: torch.Tensor, model_config, engine_config, infer_state,
+                                    cur_layer: int, o: torch.Tensor):
+    """Pure-decode batches: rotary + KV-store + paged attention in one launch, fed by the split-K partial slabs
+    of the fused qkv projection (kernels/linear.py: SplitKPartials). Same bits as
+    rotary_embedding_and_store_kvcache_decode_from_splitk followed by paged_attention; q/k/v never exist as
+    tensors (the rotated k and the v go to the pools, q stays in the kernel)."""
+    nd = infer_state.num_decoding_seqs
+    if nd == 0:
+        return
+    h, kvh, d = model_config.num_q_heads, model_config.num_kv_heads, model_config.head_dim
+    assert infer_state.num_prefill_seqs == 0 and infer_state.position_indices is not None
+    assert partials.shape == (nd, (h + 2 * kvh) * d) and partials.dtype == k_cache.dtype == o.dtype
+    assert k_cache.is_contiguous() and v_cache.is_contiguous() and block_table.is_contiguous()
+    if o.dim() == 2:
+        o = o.view(o.shape[0], h, d)
+    nsb = infer_state.num_seq_blocks
+    scratch = None
+    if nsb > 1:
+        need = _hip.scratch_bytes(nd, h, d, nsb)
+        scratch = getattr(infer_state, "paged_attn_scratch", None)
+        if scratch is None or scratch.numel() * scratch.element_size() < need:
+            scratch = torch.empty(need // 4, dtype=torch.float32, device=o.device)
+    _hip.call("swl_paged_attn_decode_qkv", _hip.ptr(o), _hip.ptr(partials.slabs), partials.k_splits,
+              _hip.ptr(infer_state.position_cos), _hip.ptr(infer_state.position_sin),
+              _hip.ptr(infer_state.position_indices), _hip.ptr(k_cache), _hip.ptr(v_cache), _hip.ptr(block_table),
+              _hip.ptr(infer_state.seq_ids), _hip.ptr(infer_state.decoding_seq_lens), _hip.ptr(scratch),
+              infer_state.softmax_scale, nd, h, kvh, d, model_config.num_layers, engine_config.block_size,
+              cur_layer, block_table.shape[1], infer_state.seq_block_size, nsb, token_stride(o, "o"),
+              _hip.dtype_code(o.dtype), _hip.stream())

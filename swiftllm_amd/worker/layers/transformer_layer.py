@@ -28,7 +28,7 @@ from ..kernels.rotary_emb import (rotary_embedding_inplace, rotary_embedding_and
                                   rotary_embedding_and_store_kvcache_decode_from_splitk)
 from ..kernels.kvcache_mgmt import store_kvcache
 from ..kernels.prefill_attn import prefill_attention
-from ..kernels.paged_attn import paged_attention
+from ..kernels.paged_attn import paged_attention, paged_attention_from_qkv_splitk
 from ..kernels.silu_and_mul import silu_and_mul_inplace
 
 
@@ -114,6 +114,14 @@ class LlamaTransformerLayer:
         fused_rope_store = (pure_decode and not st.ignore_kvcache and st.position_indices is not None
                             and getattr(ecfg, "fuse_rope_kvstore", False))
         fast = self.skinny and pure_decode and getattr(ecfg, "fuse_splitk_consumers", True)
+        if (fast and fused_rope_store and w.qkv_proj is not None and getattr(ecfg, "fuse_rope_into_attention", True)
+                and cfg.head_dim in (32, 64, 128)):
+            # fused qkv slabs -> (rotary + KV store + paged attention) in one launch
+            qkv = linear_splitk(input_embds, w.qkv_proj, always=True)
+            if isinstance(qkv, SplitKPartials):
+                paged_attention_from_qkv_splitk(qkv, k_cache, v_cache, block_table, cfg, ecfg, st, self.layer_id,
+                                                input_embds)
+                return self._forward_after_attention(input_embds, residual_buf, fast)
         if fast and fused_rope_store and w.qkv_proj is not None:
             qkv = linear_splitk(input_embds, w.qkv_proj)
             if isinstance(qkv, SplitKPartials):
@@ -155,7 +163,10 @@ class LlamaTransformerLayer:
             assert not st.ignore_kvcache
             paged_attention(q, k_cache, v_cache, block_table, cfg, ecfg, st, self.layer_id, o)
         q = k = v = None
+        return self._forward_after_attention(input_embds, residual_buf, fast)
 
+    def _forward_after_attention(self, input_embds, residual_buf, fast: bool):
+        cfg, w = self.model_config, self.weight
         if fast:
             attn_out = linear_splitk(input_embds, w.o_proj)
             if isinstance(attn_out, SplitKPartials):

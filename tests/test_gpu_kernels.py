@@ -707,3 +707,41 @@ def test_gemm_qkv_rope_store_epilogue(dtype, H, KVH, D, hid, pending_norm):
                 assert ((a.float() - b.float()).abs() <= eps * b.float().abs() + 2e-3).all()
         else:
             assert torch.equal(q2, q1) and torch.equal(kc2, kc1) and torch.equal(vc2, vc1)
+
+
+# ---- paged attention with rotary + KV store in its prologue ------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sbs", [64, 1024])      # several splits (only the last owns the new token) / one split
+@pytest.mark.parametrize("H,KVH,D,hid", [(32, 8, 128, 4096), (8, 8, 128, 512), (8, 1, 128, 1024), (8, 4, 64, 256),
+                                         (4, 2, 32, 128)])
+def test_paged_attention_from_qkv_slabs_equals_three_kernels(dtype, sbs, H, KVH, D, hid):
+    """qkv slabs -> [rotary + KV store + paged attention] in one launch == split-K rotary/store kernel followed by
+    the paged-attention kernel: outputs and both pools bit for bit (k_splits > 1 and the single-slab case)."""
+    from swiftllm_amd.worker.kernels.linear import linear_splitk, SplitKPartials
+    from swiftllm_amd.worker.kernels.paged_attn import paged_attention_from_qkv_splitk
+    from swiftllm_amd.worker.kernels.rotary_emb import rotary_embedding_and_store_kvcache_decode_from_splitk
+    g = gen(H * 3 + D + hid + sbs)
+    L, layer = 2, 1
+    lens = [1, 15, 16, 17, 63, 64, 65, 300, 129]
+    nd = len(lens)
+    _, kc, vc, bt, seq_ids = _paged_case(g, H, KVH, D, L, lens, dtype, layer)
+    n = (H + 2 * KVH) * D
+    x = torch.randn(nd, hid, generator=g).to(dtype).cuda()
+    wqkv = (torch.randn(n, hid, generator=g) * (hid ** -0.5)).to(dtype).cuda()
+    ang = torch.rand(512, D // 2, generator=g) * 6.28
+    st = _paged_state(lens, seq_ids, sbs, D, "cuda")
+    st.position_cos, st.position_sin = torch.cos(ang).to(dtype).cuda(), torch.sin(ang).to(dtype).cuda()
+    st.position_indices = torch.tensor([v - 1 for v in lens], dtype=torch.int32, device="cuda")
+    mc, ec = NS(num_q_heads=H, num_kv_heads=KVH, head_dim=D, num_layers=L), NS(block_size=16)
+    part = linear_splitk(x, wqkv, always=True)
+    assert isinstance(part, SplitKPartials)
+    kc1, vc1, btc = kc.cuda(), vc.cuda(), bt.cuda()
+    q1, _, _ = rotary_embedding_and_store_kvcache_decode_from_splitk(part, kc1, vc1, btc, mc, ec, st, layer)
+    o1 = torch.zeros(nd, H, D, dtype=dtype, device="cuda")
+    K().paged_attention(q1, kc1, vc1, btc, mc, ec, st, layer, o1)
+    kc2, vc2 = kc.cuda(), vc.cuda()
+    o2 = torch.zeros(nd, H * D, dtype=dtype, device="cuda")
+    paged_attention_from_qkv_splitk(part, kc2, vc2, btc, mc, ec, st, layer, o2)
+    assert torch.equal(o2.view(nd, H, D), o1)
+    assert torch.equal(kc2, kc1) and torch.equal(vc2, vc1)
+    assert not torch.equal(kc2.cpu(), kc)                      # the new token really went into the pool

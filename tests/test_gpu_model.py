@@ -33,9 +33,10 @@ def _make_model(tmp_path, cfg, sd, num_blocks=24, **kw):
 @pytest.mark.parametrize("opts", [dict(), dict(fuse_qkv=False, use_skinny_gemm=False),
                                   dict(fuse_qkv=False), dict(use_skinny_gemm=False),
                                   dict(fuse_rope_kvstore=False), dict(use_hip_graph=True),
-                                  dict(fuse_decode_layer=True), dict(fuse_decode_layer=True, use_hip_graph=True)],
+                                  dict(fuse_decode_layer=True), dict(fuse_decode_layer=True, use_hip_graph=True),
+                                  dict(fuse_rope_into_attention=False)],
                          ids=["default", "reference_blas_calls", "unfused_qkv", "blas_gemm", "unfused_rope",
-                              "hipgraph", "fused_layer", "fused_layer_hipgraph"])
+                              "hipgraph", "fused_layer", "fused_layer_hipgraph", "rope_kernel"])
 def test_forward_matches_reference_golden(tmp_path, golden, opts):
     """The scripted run frozen from the reference (fp16, BASELINE configs[0] model)."""
     g = golden("e2e_tiny_fp16.pt")

@@ -205,7 +205,12 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
     };
 
     int b = tok_begin / kBlk + wave;
-    if (b < blk_end) load_block(b, Ka, Va); // first: the KV stream starts while the prologue below runs
+    if constexpr (QKV) { // first: two blocks per wave are streaming while the prologue below runs
+        if (b < blk_end) load_block(b, Ka, Va);
+        if (b + NW < blk_end) load_block(b + NW, Kb, Vb);
+    } else {
+        if (b < blk_end) load_block(b, Ka, Va);
+    }
     if constexpr (QKV) {
         const bool owner = tok_end == len; // the split that attends (and stores) the new token
         constexpr int kRot = D / 16;         // rotation items per head
@@ -250,8 +255,10 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
         for (int g = 0; g < G; ++g) qv[g] = *reinterpret_cast<const vec8_t<T> *>(&sm_q[g * D + chunk * 8]);
     }
     if (b < blk_end) {
+        bool second_in_flight = QKV;
         while (true) {
-            if (b + NW < blk_end) load_block(b + NW, Kb, Vb);
+            if (!second_in_flight && b + NW < blk_end) load_block(b + NW, Kb, Vb);
+            second_in_flight = false;
             attend(b, Ka, Va);
             b += NW;
             if (b >= blk_end) break;

@@ -244,3 +244,21 @@ def test_engine_serving_matches_offline_generation(tmp_path, mode):
     assert got == expected
     assert eng.num_forwards < sum(n for _, n in shapes)      # requests really shared forwards
     assert model.gpu_block_manager.num_free_blocks == 48     # everything released
+
+
+def test_streaming_weight_loader_equals_per_tensor_loader(tmp_path):
+    """Pinned-ring streaming safetensors loader: same tensors on the device as the reference's per-tensor path,
+    fused [q;k;v] and [up;gate] assembled in place."""
+    from swiftllm_amd import LlamaModelConfig
+    from swiftllm_amd.worker.weight import load_weights
+    cfg = synth.make_config(**synth.SMALL128)
+    sd = synth.make_state_dict(cfg, seed=21)
+    synth.write_model_dir(str(tmp_path), cfg, sd)
+    mc = LlamaModelConfig.load_from_model_path(str(tmp_path))
+    a = load_weights(mc, torch.float16, str(tmp_path), device="cuda", fuse_qkv=True, streaming=True)
+    b = load_weights(mc, torch.float16, str(tmp_path), device="cuda", fuse_qkv=True, streaming=False)
+    for attr in ("wte", "lm_head", "final_norm"):
+        assert torch.equal(getattr(a, attr), getattr(b, attr)) and getattr(a, attr).is_cuda
+    for la, lb in zip(a.layers, b.layers):
+        for attr in ("attn_norm", "qkv_proj", "o_proj", "ffn_norm", "up_gate_proj", "down_proj"):
+            assert torch.equal(getattr(la, attr), getattr(lb, attr))

@@ -211,14 +211,15 @@ def test_model_config_fields_and_kvslot_size():
         LlamaModelConfig(dict(synth.make_config(), model_type="gpt2"))
 
 
-@pytest.mark.parametrize("fmt", ["safetensors", "bin"])
+@pytest.mark.parametrize("fmt", ["safetensors", "safetensors_per_tensor", "bin"])
 @pytest.mark.parametrize("fuse_qkv", [False, True])
 def test_weight_loading_on_cpu(tmp_path, fmt, fuse_qkv):
     cfg = synth.make_config()
     sd = synth.make_state_dict(cfg, seed=3)
-    synth.write_model_dir(str(tmp_path), cfg, sd, fmt=fmt)
+    synth.write_model_dir(str(tmp_path), cfg, sd, fmt=fmt.split("_")[0])
     mc = LlamaModelConfig.load_from_model_path(str(tmp_path))
-    w = load_weights(mc, torch.float16, str(tmp_path), device="cpu", fuse_qkv=fuse_qkv)
+    w = load_weights(mc, torch.float16, str(tmp_path), device="cpu", fuse_qkv=fuse_qkv,
+                     streaming=fmt != "safetensors_per_tensor")
     assert torch.equal(w.wte, sd["model.embed_tokens.weight"])
     assert torch.equal(w.lm_head, sd["lm_head.weight"])
     l1 = w.layers[1]
@@ -226,8 +227,25 @@ def test_weight_loading_on_cpu(tmp_path, fmt, fuse_qkv):
     assert torch.equal(l1.up_gate_proj, torch.cat((up, gate)))      # [up ; gate], weight.py:133
     if fuse_qkv:
         assert l1.qkv_proj.shape == (128 + 2 * 64, 128) and not hasattr(l1, "q_proj")
+        assert torch.equal(l1.qkv_proj, torch.cat([sd[f"model.layers.1.self_attn.{n}_proj.weight"] for n in "qkv"]))
     else:
         assert torch.equal(l1.k_proj, sd["model.layers.1.self_attn.k_proj.weight"])
+    assert torch.equal(l1.down_proj, sd["model.layers.1.mlp.down_proj.weight"])
+    assert torch.equal(w.final_norm, sd["model.norm.weight"])
+
+
+def test_streaming_loader_converts_dtype_through_the_per_tensor_path_and_checks_shapes(tmp_path):
+    cfg = synth.make_config()
+    sd = synth.make_state_dict(cfg, seed=4)
+    synth.write_model_dir(str(tmp_path), cfg, sd)
+    mc = LlamaModelConfig.load_from_model_path(str(tmp_path))
+    w = load_weights(mc, torch.bfloat16, str(tmp_path), device="cpu", fuse_qkv=True)      # fp16 file, bf16 run
+    assert w.wte.dtype == torch.bfloat16 and torch.equal(w.wte, sd["model.embed_tokens.weight"].to(torch.bfloat16))
+    bad = dict(sd)
+    bad["model.layers.0.mlp.down_proj.weight"] = bad["model.layers.0.mlp.down_proj.weight"][:, :-1].contiguous()
+    synth.write_model_dir(str(tmp_path), cfg, bad)
+    with pytest.raises(AssertionError, match="does not match"):
+        load_weights(mc, torch.float16, str(tmp_path), device="cpu")
 
 
 def test_dummy_weights_and_tied_head(tmp_path):

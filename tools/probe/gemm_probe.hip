@@ -387,3 +387,25 @@ extern "C" int probe_ring(int nw, int depth, int occ, void *out, const void *x, 
 #undef RCASE
     return -3;
 }
+
+// ---- prefetch probe: touch the first `bytes_per_row` of every row of W (what the GEMM's first tiles read) ----
+__global__ __launch_bounds__(256) void prefetch_rows_kernel(const char *w, long long row_pitch, int rows_per_wg,
+                                                            int bytes_per_row, int *sink) {
+    // WG j touches the rows GEMM workgroup j will stream first (consecutive WGs -> consecutive XCDs, as there)
+    const int per_row = bytes_per_row / 16;
+    const int items = rows_per_wg * per_row;
+    unsigned acc = 0;
+    for (int it = threadIdx.x; it < items; it += 256) {
+        const int r = it / per_row, c = it % per_row;
+        const uint4 v = *reinterpret_cast<const uint4 *>(w + (static_cast<long long>(blockIdx.x) * rows_per_wg + r) * row_pitch + c * 16);
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345678u) *sink = 1; // never true in practice: keeps the loads alive
+}
+
+extern "C" int probe_prefetch(const void *w, long long row_pitch, int rows, int rows_per_wg, int bytes_per_row,
+                              void *sink, void *stream) {
+    hipLaunchKernelGGL(prefetch_rows_kernel, dim3(rows / rows_per_wg), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const char *>(w), row_pitch, rows_per_wg, bytes_per_row, static_cast<int *>(sink));
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""gemm_silu_micro.py — the up/gate projection + SiLU-gate of one Llama-3-8B decode layer (M tokens) launched
+`iters` times over `copies` distinct weight matrices (so every launch streams from HBM). Used under
+rocprofv3 --pmc (tools/gpu_pmc_gemm.sh) to compare HBM traffic with the algorithmic bytes."""
+import argparse, json, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from swiftllm_amd import _hip
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--m", type=int, default=32)
+ap.add_argument("--iters", type=int, default=64)
+ap.add_argument("--copies", type=int, default=16)
+a = ap.parse_args()
+I, K = 14336, 4096
+ws = [torch.empty(2 * I, K, dtype=torch.bfloat16, device="cuda").normal_(0, 0.02) for _ in range(a.copies)]
+x = torch.randn(a.m, K, device="cuda").bfloat16()
+out = torch.empty(a.m, I, dtype=torch.bfloat16, device="cuda")
+st = torch.cuda.current_stream().cuda_stream
+def launch(i):
+    _hip.call("swl_gemm_skinny_silu_gate", out.data_ptr(), x.data_ptr(), ws[i % a.copies].data_ptr(), a.m, I, K, K, I, 1, st)
+for i in range(4):
+    launch(i)
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda.synchronize(); s.record()
+for i in range(a.iters):
+    launch(i)
+e.record(); e.synchronize()
+us = s.elapsed_time(e) * 1e3 / a.iters
+alg = 2 * I * K * 2 + a.m * K * 2 + a.m * I * 2
+print(json.dumps({"kernel": "gemm_skinny_ring_kernel<bf16, SiluGate>", "M": a.m, "I": I, "K": K, "us": round(us, 2),
+                  "algorithmic_bytes": alg, "TBps": round(alg / us / 1e6, 3)}))

@@ -28,7 +28,6 @@
 //     (grid.y): each split writes an fp32 partial slab, a second tiny kernel adds the slabs in a fixed
 //     order and rounds once. Deterministic, no atomics.
 #include "swl_common.h"
-#include <cstdlib>
 
 namespace swl {
 
@@ -80,7 +79,6 @@ struct GemmFuse {
     const int *block_table, *seq_ids, *seq_lens;
     int H, KVH, D, cur_layer, num_layers, block_size, max_blocks_per_seq;
     int64_t q_tok_stride;
-    int debug; // SWL_EPI_DEBUG (probing only): 1 = stop after the slab stores, 2 = stop after the count, 3 = always coherent loads
 };
 
 // Which of the chip's XCDs (each with its own L2) this wave runs on: HW_REG_XCC_ID, bits [3:0].
@@ -201,7 +199,6 @@ template <typename T, int EPI>
 __device__ __forceinline__ void splitk_finish(const GemmFuse &f, const float *slabs, int *flag_lds, int M,
                                               int N) {
     if constexpr (EPI != kEpiNone) {
-        if (f.debug == 1) return;
         // the residual tile does not depend on the slabs: every workgroup fetches it before the count (8 KiB,
         // wasted in all but the last arriver) so its HBM latency is off the last arriver's critical path
         vec8_t<T> res_in[2] = {};
@@ -215,8 +212,8 @@ __device__ __forceinline__ void splitk_finish(const GemmFuse &f, const float *sl
             }
         }
         const int state = splitk_arrive(f.counters, flag_lds);
-        if (state == 0 || f.debug == 2) return;
-        if (state == 1 && f.debug != 3) {
+        if (state == 0) return;
+        if (state == 1) {
             if constexpr (EPI == kEpiAddResidual) epi_add_residual<T, false>(f, slabs, M, N, res_in);
             else epi_rope_store<T, false>(f, slabs, M, N);
         } else {
@@ -714,8 +711,7 @@ static int run_fused_partial(const T *x, const T *w, float *slabs, size_t slabs_
     const int ks = choose_k_splits(N, K);
     if (slabs_bytes < static_cast<size_t>(ks) * M * N * sizeof(float) || counters_len < N / 128)
         return SWL_ERR_BAD_ARG;
-    GemmFuse f = f_in;
-    if (const char *dbg = getenv("SWL_EPI_DEBUG")) f.debug = atoi(dbg);
+    const GemmFuse &f = f_in;
     const int kc = K / ks;
     const dim3 grid(N / 128, ks), block(kGemmWaves * 64);
     const int64_t os = N;

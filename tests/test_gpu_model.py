@@ -262,3 +262,68 @@ def test_streaming_weight_loader_equals_per_tensor_loader(tmp_path):
     for la, lb in zip(a.layers, b.layers):
         for attr in ("attn_norm", "qkv_proj", "o_proj", "ffn_norm", "up_gate_proj", "down_proj"):
             assert torch.equal(getattr(la, attr), getattr(lb, attr))
+
+
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_full_width_layers_fast_path_equals_reference_op_sequence(tmp_path, dtype):
+    """Llama-3-8B layer geometry (hidden 4096, 32/8 heads of 128, FFN 14336; 2 layers, 8k vocabulary so the CPU
+    side stays small): here every decode projection really splits K (4-8 slabs), runs the ring kernel, the
+    split-K consumers and the attention kernel fed by qkv slabs — none of which the small test models reach. The
+    default path must give the tokens of the reference's op sequence (separate q/k/v, every linear on hipBLASLt,
+    one kernel per operator), with logits inside the storage dtype's rounding, with and without hipGraph replay,
+    and with the experimental fused layer."""
+    cfg = synth.make_config(num_hidden_layers=2, hidden_size=4096, num_attention_heads=32, num_key_value_heads=8,
+                            intermediate_size=14336, vocab_size=8192, max_position_embeddings=2048,
+                            rope_theta=500000.0)
+    tdtype = torch.float16 if dtype == "float16" else torch.bfloat16
+    sd = synth.make_state_dict(cfg, seed=31, dtype=tdtype)
+    g = torch.Generator().manual_seed(8)
+    lens = [1, 15, 16, 17, 100, 257, 640, 33] * 4                 # batch 32, ragged
+    prompts = [torch.randint(0, cfg["vocab_size"], (n,), generator=g).tolist() for n in lens]
+    base = dict(max_blocks_per_seq=64, max_tokens_in_batch=8192, max_batch_size=32, max_seqs_in_block_table=32,
+                dtype=dtype)
+    from swiftllm_amd import LlamaModel
+    synth.write_model_dir(str(tmp_path), cfg, sd)
+    del sd
+    seq_ids = list(range(len(prompts)))
+
+    def run(opts, forced=None):
+        """prefill + 6 decode steps; `forced` = token lists to feed instead of the run's own (teacher forcing: one
+        near-tie must not make the later steps incomparable)"""
+        model = LlamaModel(_engine_config(str(tmp_path), **base, **opts))
+        model.load_weights()
+        model.init_kvcache_and_swap(32 * 48)
+        model.post_layer.logits_tap = []
+        tap = model.post_layer.logits_tap
+        toks = [model.forward(prompts, seq_ids, [])]
+        logits = [tap[-1].float().cpu()]        # copied at once: under hipGraph replay the tapped tensor is reused
+        cur = list(lens)
+        for step in range(6):
+            cur = [n + 1 for n in cur]
+            feed = forced[step] if forced is not None else toks[-1]
+            toks.append(model.forward([[t] for t in feed], seq_ids, list(cur)))
+            logits.append(tap[-1].float().cpu())
+        del model
+        torch.cuda.empty_cache()
+        return toks, logits
+
+    ref_toks, ref_logits = run(dict(fuse_qkv=False, use_skinny_gemm=False))
+    eps = 2.0 ** -10 if dtype == "float16" else 2.0 ** -7
+    results = {}
+    for name, opts in (("default", dict()), ("hipgraph", dict(use_hip_graph=True)),
+                       ("fused_layer", dict(fuse_decode_layer=True))):
+        toks, logits = run(opts, forced=ref_toks)
+        results[name] = toks
+        for step, (a, b) in enumerate(zip(logits, ref_logits)):
+            # budget: a few ulps of the storage dtype AT THE SCALE OF THE ROW (16-bit activation flips upstream move
+            # small logits by as much as large ones)
+            scale = b.abs().amax(dim=1, keepdim=True).clamp(min=1.0)
+            excess = ((a - b).abs() - 4 * eps * scale).max().item()
+            assert excess <= 0, (name, step, excess)
+        # greedy ids: identical except where the reference run itself has a near-tie
+        for step, (a, b) in enumerate(zip(toks, ref_toks)):
+            for seq, (x, y) in enumerate(zip(a, b)):
+                if x != y:
+                    top2 = ref_logits[step][seq].topk(2).values
+                    assert float(top2[0] - top2[1]) <= 8 * eps * float(top2[0].abs().clamp(min=1.0)), (name, step, seq)
+    assert results["default"] == results["hipgraph"]

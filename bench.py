@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--no-splitk-fusion", dest="splitk_fusion", action="store_false")
     ap.add_argument("--layer-fusion", dest="layer_fusion", action="store_true",
                     help="fold norm/rotary/residual hand-offs into the GEMMs (experimental, slower: DESIGN.md §4.4)")
+    ap.add_argument("--no-packed-weights", dest="packed_weights", action="store_false")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-iters", type=int, default=256)
     return ap.parse_args()
@@ -98,7 +99,8 @@ def build_model(args, cfg, num_blocks):
                       max_batch_size=args.batch, max_tokens_in_batch=args.batch * args.prompt_len,
                       dtype=args.dtype, fuse_qkv=args.fuse_qkv, use_hip_graph=not args.no_hip_graph,
                       use_skinny_gemm=args.skinny_gemm, fuse_splitk_consumers=args.splitk_fusion,
-                      fuse_decode_layer=getattr(args, "layer_fusion", False))
+                      fuse_decode_layer=getattr(args, "layer_fusion", False),
+                      pack_decode_weights=getattr(args, "packed_weights", True))
     model = LlamaModel(ec)
     model.load_weights()
     # random-init weights of the named architecture: N(0, 0.02^2) matrices, norm weights 1 + N(0, 0.02^2)
@@ -114,6 +116,7 @@ def build_model(args, cfg, num_blocks):
                 t.normal_(0.0, 0.02, generator=g).add_(1.0)
             else:
                 t.normal_(0.0, 0.02, generator=g)
+    model.repack_decode_weights()       # the packed decode copies follow the re-initialised weights
     model.init_kvcache_and_swap(num_blocks)
     return model
 
@@ -204,9 +207,12 @@ def gemm_roofline(model, batch, iters):
     out = torch.empty(M, I, device=model.device, dtype=model.dtype)
     code = _hip.dtype_code(model.dtype)
 
+    packed = all(getattr(l.up_gate_proj, "_swl_packed", None) is not None for l in layers)
+    fn = "swl_gemm_skinny_packed_silu_gate" if packed else "swl_gemm_skinny_silu_gate"
+    srcs = [(l.up_gate_proj._swl_packed if packed else l.up_gate_proj) for l in layers]
+
     def launch(i):
-        _hip.call("swl_gemm_skinny_silu_gate", out.data_ptr(), x.data_ptr(), layers[i % len(layers)].up_gate_proj.data_ptr(),
-                  M, I, K, K, I, code, _hip.stream())
+        _hip.call(fn, out.data_ptr(), x.data_ptr(), srcs[i % len(srcs)].data_ptr(), M, I, K, K, I, code, _hip.stream())
     for i in range(min(iters, len(layers))):
         launch(i)
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -227,7 +233,7 @@ def gemm_roofline(model, batch, iters):
             pmc = json.load(f)
         traffic = int(alg_bytes * pmc["traffic_over_algorithmic"])
         src = "profiles/r01e_gemm_silu_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, scaled by bytes)"
-    return dict(bound="hbm", kernel="gemm_skinny_ring_kernel<SiluGate> (up/gate projection + SiLU-gate)",
+    return dict(bound="hbm", kernel="gemm_skinny_ring_kernel<SiluGate%s> (up/gate projection + SiLU-gate)" % (", packed W" if packed else ""),
                 achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
                 frac_of_measured_copy=round(gbs / HBM_COPY_GBS, 4), traffic=traffic, traffic_source=src,
                 bytes_per_launch=int(alg_bytes), us_per_launch=round(us, 2), launches=iters)
@@ -351,7 +357,8 @@ def main():
                    "global_batch": B * world, "prompt_len": S, "gen_len": gen_total,
                    "parallelism": f"request-sharded dp{world} (independent replicas, no collective)",
                    "hip_graph": not args.no_hip_graph, "fuse_qkv": args.fuse_qkv,
-                   "skinny_gemm": args.skinny_gemm, "kv_blocks": num_blocks},
+                   "skinny_gemm": args.skinny_gemm, "packed_decode_weights": getattr(args, "packed_weights", True),
+                   "kv_blocks": num_blocks},
         "prefill_tok_s": round(prefill_units / prefill_max_s, 1),
         "prefill_ms": round(prefill_max_s * 1e3, 2),
         "step_roofline": {"bound": "hbm", "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

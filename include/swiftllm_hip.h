@@ -238,6 +238,23 @@ int swl_gemm_skinny_silu_gate(void *out, const void *x, const void *w_up_gate, i
                               int32_t K, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype,
                               swl_stream_t stream);
 
+/* ---- Pre-packed weights -----------------------------------------------------------------------------------------
+ * swl_gemm_pack_weight repacks W[N, K] once (load time) into MFMA-fragment order [N/32][K/16][64 lanes][8 elements]:
+ * the A operand of a 32x32x16 MFMA becomes one contiguous KiB and a wave's K range for its 32 rows one sequential
+ * run, so the decode GEMMs read W with long DRAM bursts and without an LDS transpose (6.0-6.3 instead of 5.3-5.8
+ * TB/s). The *_packed entry points take the packed copy and otherwise behave exactly like their row-major twins
+ * (same arguments, same bits). N % 32 == 0, K % 128 == 0 (pack: K % 16 == 0), M <= 32. */
+int swl_gemm_pack_weight(void *dst, const void *src, int32_t N, int32_t K, int32_t dtype, swl_stream_t stream);
+int swl_gemm_skinny_packed(void *out, const void *x, const void *w_packed, void *workspace, size_t workspace_bytes,
+                           int32_t M, int32_t N, int32_t K, int64_t x_row_stride, int64_t out_row_stride,
+                           int32_t k_splits, int32_t dtype, swl_stream_t stream);
+int swl_gemm_skinny_packed_partial(float *slabs, size_t slabs_bytes, const void *x, const void *w_packed, int32_t M,
+                                   int32_t N, int32_t K, int64_t x_row_stride, int32_t k_splits, int32_t dtype,
+                                   swl_stream_t stream);
+int swl_gemm_skinny_packed_silu_gate(void *out, const void *x, const void *w_up_gate_packed, int32_t M, int32_t I,
+                                     int32_t K, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype,
+                                     swl_stream_t stream);
+
 /* ---- Fused decode layer: the latency-bound hand-offs between the projections folded into the GEMMs --------
  * (reference: transformer_layer.py:31-130 runs fused_add_rmsnorm / rotary / store_kvcache as separate
  * kernels between the linears). Split-K workgroups that share an output tile count themselves in; the last one

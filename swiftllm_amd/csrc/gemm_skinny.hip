@@ -374,15 +374,22 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_skinny_kernel(
 constexpr int kRing = 3;
 constexpr int kMaxNormK = 4096; // XNORM: K-chunk whose norm weight fits the 8 KiB LDS slice
 
-template <typename T, int MODE, bool XNORM = false, int EPI = kEpiNone>
-// 2 waves per SIMD: the ring holds 3 x 8 KiB of W per wave in registers (~220 VGPRs)
+// PACKED: W comes pre-packed in MFMA-fragment order (swl_gemm_pack_weight: [N/32][K/16][64 lanes][8]) — the A
+// operand of one v_mfma_f32_32x32x16 is ONE contiguous KiB and a wave's whole K range for its 32 rows one
+// contiguous run of K*64 bytes. Loads go global -> VGPR -> MFMA: no LDS round trip for W, and the DRAM sees long
+// sequential bursts instead of 32 row segments of 256 B per tile (stream probe: 5.7-5.9 TB/s with 256-B row
+// segments, 6.2-6.4 TB/s with KiB runs). Same MFMA order as the row-major kernels, hence the same bits. RD = ring
+// depth (3 for K-chunks of >= 8 tiles, 2 for shorter ones).
+template <typename T, int MODE, bool XNORM = false, int EPI = kEpiNone, bool PACKED = false, int RD = kRing>
+// 2 waves per SIMD: the ring holds RD x 8 KiB of W per wave in registers (~220 VGPRs at RD = 3)
 __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_skinny_ring_kernel(
     void *__restrict__ out_, const T *__restrict__ x, const T *__restrict__ w, int M, int N, int K,
     int kc, int64_t x_stride, int64_t out_stride, GemmFuse fuse) {
-    constexpr int D = kRing;
+    static_assert(!PACKED || (!XNORM && EPI == kEpiNone), "the fusion hooks are built on the row-major kernels");
+    constexpr int D = RD;
     constexpr int XL = 8 / kGemmWaves; // x row-groups (4 rows each) a wave stages per tile
-    // [0..1] the double-buffered x tile of the workgroup, [2 + wave] the wave-private W tile
-    __shared__ __attribute__((aligned(16))) T lds[2 + kGemmWaves][32 * kKT];
+    // [0..1] the double-buffered x tile of the workgroup, [2 + wave] the wave-private W tile (row-major W only)
+    __shared__ __attribute__((aligned(16))) T lds[2 + (PACKED ? 0 : kGemmWaves)][32 * kKT];
     __shared__ __attribute__((aligned(16))) T gl[XNORM ? kMaxNormK : 8]; // norm weight of the K-chunk
     __shared__ float rs[32];                                              // XNORM: 1/rms per row
 
@@ -399,7 +406,10 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_skinny_ring_kernel(
 
     const int rsub = lane >> 4;
     const int chunk = lane & 15;
-    const T *wsrc = w + static_cast<int64_t>(n0 + rsub) * K + k_begin + chunk * 8;
+    // row-major: lane -> (row 4i + lane/16, 16-byte chunk lane%16) of tile i; packed: lane -> its fragment slot of
+    // block (n0/32, k/16), blocks of 512 elements back to back along k
+    const T *wsrc = PACKED ? w + (static_cast<int64_t>(n0 / 32) * (K / 16) + k_begin / 16) * 512 + lane * 8
+                           : w + static_cast<int64_t>(n0 + rsub) * K + k_begin + chunk * 8;
     int lds_wr[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -416,7 +426,7 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_skinny_ring_kernel(
     }
     const int l32 = lane & 31;
     const int hf = lane >> 5;
-    T *wl = &lds[2 + wave][0];
+    T *wl = &lds[PACKED ? 0 : 2 + wave][0]; // (unused when PACKED)
 
     float rstd[XL];
 
@@ -427,7 +437,8 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_skinny_ring_kernel(
     {                                                                                                \
         _Pragma("unroll") for (int q_ = 0; q_ < XL; ++q_) xr[slot][q_] = load8(xsrc[q_] + (tile) * kKT); \
         _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                             \
-            wr[slot][i_] = load8_nt(wsrc + static_cast<int64_t>(4 * i_) * K + (tile) * kKT);         \
+            wr[slot][i_] = PACKED ? load8_nt(wsrc + (static_cast<int64_t>(tile) * 8 + i_) * 512)     \
+                                  : load8_nt(wsrc + static_cast<int64_t>(4 * i_) * K + (tile) * kKT); \
     }
 #define SWL_STAGE_X(slot, buf, tile)                                                                 \
     {                                                                                                \
@@ -443,12 +454,16 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_skinny_ring_kernel(
     }
 #define SWL_PROCESS(slot, buf)                                                                       \
     {                                                                                                \
-        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                             \
-            *reinterpret_cast<vec8_t<T> *>(wl + lds_wr[i_]) = wr[slot][i_];                          \
+        if constexpr (!PACKED) {                                                                     \
+            _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                         \
+                *reinterpret_cast<vec8_t<T> *>(wl + lds_wr[i_]) = wr[slot][i_];                      \
+        }                                                                                            \
         const T *xl_ = &lds[buf][0];                                                                 \
         _Pragma("unroll") for (int kk_ = 0; kk_ < kKT / 16; ++kk_) {                                 \
             const int off_ = l32 * kKT + (((2 * kk_ + hf) ^ (l32 & 15)) << 3);                       \
-            const vec8_t<T> a_ = *reinterpret_cast<const vec8_t<T> *>(wl + off_);                    \
+            vec8_t<T> a_;                                                                            \
+            if constexpr (PACKED) a_ = wr[slot][kk_];                                                \
+            else a_ = *reinterpret_cast<const vec8_t<T> *>(wl + off_);                               \
             const vec8_t<T> b_ = *reinterpret_cast<const vec8_t<T> *>(xl_ + off_);                   \
             acc = mfma32x32x16(a_, b_, acc);                                                         \
         }                                                                                            \
@@ -517,9 +532,17 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_skinny_ring_kernel(
 #undef SWL_ISSUE
 #undef SWL_STAGE_X
 #undef SWL_PROCESS
-    gemm_epilogue<T, MODE, EPI != kEpiNone>(acc, out_, &lds[2][0], 32 * kKT, wave, lane, is_gate, tile_ok, col0, n0, ksplit, M,
-                           N, out_stride);
-    splitk_finish<T, EPI>(fuse, static_cast<const float *>(out_), reinterpret_cast<int *>(&lds[0][0]), M, N);
+    if constexpr (PACKED) {
+        // no W tiles in LDS: the SiLU-gate exchange (32 x 40 elements per wave) reuses the x buffers once every
+        // wave is done reading them
+        if constexpr (MODE == kGemmSiluGate) __syncthreads();
+        gemm_epilogue<T, MODE, false>(acc, out_, &lds[0][0], 32 * 40, wave, lane, is_gate, tile_ok, col0, n0, ksplit,
+                                      M, N, out_stride);
+    } else {
+        gemm_epilogue<T, MODE, EPI != kEpiNone>(acc, out_, &lds[PACKED ? 0 : 2][0], 32 * kKT, wave, lane, is_gate,
+                                                tile_ok, col0, n0, ksplit, M, N, out_stride);
+        splitk_finish<T, EPI>(fuse, static_cast<const float *>(out_), reinterpret_cast<int *>(&lds[0][0]), M, N);
+    }
 }
 
 // out[m][n] = round(sum over splits, in split order) — 4 outputs per thread.
@@ -845,4 +868,128 @@ extern "C" int swl_gemm_skinny_qkv_rope_store(
             static_cast<const T *>(x), static_cast<const T *>(w_qkv), slabs, slabs_bytes, counters_len, M, N, K,
             x_row_stride, f, ssq_in != nullptr, static_cast<hipStream_t>(stream));
     });
+}
+
+// ---- pre-packed weights (PACKED ring kernel) ------------------------------------------------------------------
+namespace swl {
+
+// dst[N/32][K/16][64][8]: lane l of block (nt, k16) holds src[nt*32 + l%32][k16*16 + 8*(l/32) .. +8]
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_kernel(T *__restrict__ dst, const T *__restrict__ src, int N, int K) {
+    const int64_t blocks = static_cast<int64_t>(N / 32) * (K / 16);
+    const int lane = threadIdx.x & 63;
+    for (int64_t b = blockIdx.x * 4ll + (threadIdx.x >> 6); b < blocks; b += gridDim.x * 4ll) {
+        const int64_t nt = b / (K / 16);
+        const int k16 = static_cast<int>(b - nt * (K / 16));
+        const T *s = src + (nt * 32 + (lane & 31)) * K + k16 * 16 + 8 * (lane >> 5);
+        store8(dst + (b * 64 + lane) * 8, load8(s));
+    }
+}
+
+template <typename T, int MODE>
+static void launch_packed(dim3 grid, hipStream_t stream, void *out, const T *x, const T *wp, int M, int N, int K, int kc,
+                          int64_t xs, int64_t os) {
+    if (use_ring(kc))
+        hipLaunchKernelGGL((gemm_skinny_ring_kernel<T, MODE, false, kEpiNone, true, 3>), grid, dim3(kGemmWaves * 64), 0,
+                           stream, out, x, wp, M, N, K, kc, xs, os, GemmFuse{});
+    else
+        hipLaunchKernelGGL((gemm_skinny_ring_kernel<T, MODE, false, kEpiNone, true, 2>), grid, dim3(kGemmWaves * 64), 0,
+                           stream, out, x, wp, M, N, K, kc, xs, os, GemmFuse{});
+}
+
+template <typename T>
+static int run_gemm_packed(T *out, const T *x, const T *wp, float *ws, size_t ws_bytes, int M, int N, int K, int64_t xs,
+                           int64_t os, int ks, hipStream_t stream, bool reduce) {
+    if (ks <= 0) ks = choose_k_splits(N, K);
+    if (K % (kKT * ks) != 0) return SWL_ERR_UNSUPPORTED;
+    const dim3 grid((N / 32 + kGemmWaves - 1) / kGemmWaves, ks);
+    const int kc = K / ks;
+    if (ks == 1 && reduce) {
+        launch_packed<T, kGemmDirect>(grid, stream, out, x, wp, M, N, K, kc, xs, os);
+        return check_launch();
+    }
+    if (!ws || ws_bytes < static_cast<size_t>(ks) * M * N * sizeof(float)) return SWL_ERR_BAD_ARG;
+    launch_packed<T, kGemmPartial>(grid, stream, ws, x, wp, M, N, K, kc, xs, static_cast<int64_t>(N));
+    if (!reduce) return check_launch();
+    const int64_t items = static_cast<int64_t>(M) * (N / 4);
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(static_cast<unsigned>((items + 255) / 256)), dim3(256), 0,
+                       stream, out, ws, M, N, ks, os);
+    return check_launch();
+}
+
+} // namespace swl
+
+/* dst <- W repacked in MFMA-fragment order ([N/32][K/16][64 lanes][8 elements], same size as W) for the
+ * swl_gemm_skinny_packed* entry points. Done once per weight at load time. N % 32 == 0, K % 16 == 0. */
+extern "C" int swl_gemm_pack_weight(void *dst, const void *src, int32_t N, int32_t K, int32_t dtype,
+                                    swl_stream_t stream) {
+    if (N <= 0 || K <= 0 || !dst || !src || dst == src) return SWL_ERR_BAD_ARG;
+    if ((N & 31) || (K & 15)) return SWL_ERR_UNSUPPORTED;
+    if (!swl::aligned16(dst) || !swl::aligned16(src)) return SWL_ERR_BAD_ARG;
+    const int64_t blocks = static_cast<int64_t>(N / 32) * (K / 16);
+    const unsigned grid = static_cast<unsigned>(blocks / 4 + 1 < 65536 ? blocks / 4 + 1 : 65536);
+    SWL_DISPATCH_DTYPE(dtype, T, {
+        hipLaunchKernelGGL((swl::pack_weight_kernel<T>), dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<T *>(dst), static_cast<const T *>(src), N, K);
+    });
+    return swl::check_launch();
+}
+
+/* swl_gemm_skinny / swl_gemm_skinny_partial / swl_gemm_skinny_silu_gate on a weight packed by
+ * swl_gemm_pack_weight: same arguments, same results bit for bit; K % 128 == 0, N (I) % 32 == 0, M <= 32. */
+extern "C" int swl_gemm_skinny_packed(void *out, const void *x, const void *w_packed, void *workspace,
+                                      size_t workspace_bytes, int32_t M, int32_t N, int32_t K, int64_t x_row_stride,
+                                      int64_t out_row_stride, int32_t k_splits, int32_t dtype, swl_stream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
+    if (M == 0) return SWL_OK;
+    if (!out || !x || !w_packed) return SWL_ERR_BAD_ARG;
+    if (M > 32 || (N & 31) || (K & (swl::kKT - 1))) return SWL_ERR_UNSUPPORTED;
+    if (x_row_stride < K || out_row_stride < N || (x_row_stride & 7) || (out_row_stride & 3)) return SWL_ERR_BAD_ARG;
+    if (!swl::aligned16(x) || !swl::aligned16(w_packed) || (reinterpret_cast<uintptr_t>(out) & 7u) ||
+        (workspace && !swl::aligned16(workspace)))
+        return SWL_ERR_BAD_ARG;
+    if (k_splits < 0 || k_splits > 16 || (k_splits & (k_splits - 1))) return SWL_ERR_BAD_ARG;
+    SWL_DISPATCH_DTYPE(dtype, T, {
+        return swl::run_gemm_packed<T>(static_cast<T *>(out), static_cast<const T *>(x),
+                                       static_cast<const T *>(w_packed), static_cast<float *>(workspace),
+                                       workspace_bytes, M, N, K, x_row_stride, out_row_stride, k_splits,
+                                       static_cast<hipStream_t>(stream), true);
+    });
+}
+
+extern "C" int swl_gemm_skinny_packed_partial(float *slabs, size_t slabs_bytes, const void *x, const void *w_packed,
+                                              int32_t M, int32_t N, int32_t K, int64_t x_row_stride,
+                                              int32_t k_splits, int32_t dtype, swl_stream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
+    if (M == 0) return SWL_OK;
+    if (!slabs || !x || !w_packed || k_splits < 1 || k_splits > 16 || (k_splits & (k_splits - 1)))
+        return SWL_ERR_BAD_ARG;
+    if (M > 32 || (N & 31) || (K & (swl::kKT - 1))) return SWL_ERR_UNSUPPORTED;
+    if (x_row_stride < K || (x_row_stride & 7) || !swl::aligned16(x) || !swl::aligned16(w_packed) ||
+        !swl::aligned16(slabs))
+        return SWL_ERR_BAD_ARG;
+    SWL_DISPATCH_DTYPE(dtype, T, {
+        return swl::run_gemm_packed<T>(static_cast<T *>(nullptr), static_cast<const T *>(x),
+                                       static_cast<const T *>(w_packed), slabs, slabs_bytes, M, N, K, x_row_stride, N,
+                                       k_splits, static_cast<hipStream_t>(stream), false);
+    });
+}
+
+extern "C" int swl_gemm_skinny_packed_silu_gate(void *out, const void *x, const void *w_up_gate_packed, int32_t M,
+                                                int32_t I, int32_t K, int64_t x_row_stride, int64_t out_row_stride,
+                                                int32_t dtype, swl_stream_t stream) {
+    if (M < 0 || I <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
+    if (M == 0) return SWL_OK;
+    if (!out || !x || !w_up_gate_packed) return SWL_ERR_BAD_ARG;
+    if (M > 32 || (I & 31) || (K & (swl::kKT - 1))) return SWL_ERR_UNSUPPORTED;
+    if (x_row_stride < K || out_row_stride < I || (x_row_stride & 7) || (out_row_stride & 3)) return SWL_ERR_BAD_ARG;
+    if (!swl::aligned16(x) || !swl::aligned16(w_up_gate_packed) || (reinterpret_cast<uintptr_t>(out) & 7u))
+        return SWL_ERR_BAD_ARG;
+    const dim3 grid((I / 32 + 1) / 2, 1);
+    SWL_DISPATCH_DTYPE(dtype, T, {
+        swl::launch_packed<T, swl::kGemmSiluGate>(grid, static_cast<hipStream_t>(stream), out, static_cast<const T *>(x),
+                                                  static_cast<const T *>(w_up_gate_packed), M, I, K, K, x_row_stride,
+                                                  out_row_stride);
+    });
+    return swl::check_launch();
 }

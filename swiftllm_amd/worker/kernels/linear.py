@@ -41,6 +41,27 @@ def _row_stride(a: torch.Tensor) -> int:
     return a.stride(0) if a.shape[0] > 1 else max(a.stride(0), a.shape[1])
 
 
+def pack_weight(w: torch.Tensor) -> torch.Tensor:
+    """A copy of w[N, K] in MFMA-fragment order (csrc/gemm_skinny.hip, PACKED ring kernel), attached to `w` as
+    `w._swl_packed` so that `linear(..., skinny=True)` and its split-K / SiLU-gate variants stream the packed copy
+    for decode-sized calls. Done once per weight at load time; call again after changing `w` in place."""
+    assert w.is_cuda and w.dim() == 2 and w.is_contiguous() and w.shape[0] % 32 == 0 and w.shape[1] % 128 == 0
+    wp = torch.empty_like(w)
+    _hip.call("swl_gemm_pack_weight", _hip.ptr(wp), _hip.ptr(w), w.shape[0], w.shape[1], _hip.dtype_code(w.dtype),
+              _hip.stream())
+    w._swl_packed = wp
+    return wp
+
+
+def packable(w) -> bool:
+    return (isinstance(w, torch.Tensor) and w.is_cuda and w.dim() == 2 and w.is_contiguous()
+            and w.dtype in (torch.float16, torch.bfloat16) and w.shape[0] % 32 == 0 and w.shape[1] % 128 == 0)
+
+
+def _packed_of(w: torch.Tensor):
+    return getattr(w, "_swl_packed", None)
+
+
 class SplitKPartials:
     """fp32 partial slabs [k_splits][M][N] of a projection whose K was split across workgroups.
     Lives in the shared split-K workspace: it must be consumed (or materialised) before the next
@@ -71,7 +92,9 @@ def linear(a: torch.Tensor, w: torch.Tensor, skinny: bool = False) -> torch.Tens
         out = torch.empty((m, n), dtype=a.dtype, device=a.device)
         need = _hip.load().swl_gemm_skinny_workspace_bytes(m, n, k)
         ws = _workspace(a.device, need) if need else None
-        _hip.call("swl_gemm_skinny", _hip.ptr(out), _hip.ptr(a), _hip.ptr(w), _hip.ptr(ws),
+        wp = _packed_of(w)
+        _hip.call("swl_gemm_skinny_packed" if wp is not None else "swl_gemm_skinny", _hip.ptr(out), _hip.ptr(a),
+                  _hip.ptr(wp if wp is not None else w), _hip.ptr(ws),
                   ws.numel() * 4 if ws is not None else 0, m, n, k, _row_stride(a), n, 0,
                   _hip.dtype_code(a.dtype), _hip.stream())
         return out
@@ -88,7 +111,9 @@ def linear_splitk(a: torch.Tensor, w: torch.Tensor, always: bool = False):
         ks = _hip.load().swl_gemm_skinny_choose_splits(n, k)
         if ks > 1 or (always and ks == 1):
             ws = _workspace(a.device, ks * m * n * 4)
-            _hip.call("swl_gemm_skinny_partial", _hip.ptr(ws), ws.numel() * 4, _hip.ptr(a), _hip.ptr(w), m, n, k,
+            wp = _packed_of(w)
+            _hip.call("swl_gemm_skinny_packed_partial" if wp is not None else "swl_gemm_skinny_partial", _hip.ptr(ws),
+                      ws.numel() * 4, _hip.ptr(a), _hip.ptr(wp if wp is not None else w), m, n, k,
                       _row_stride(a), ks, _hip.dtype_code(a.dtype), _hip.stream())
             return SplitKPartials(ws, ks, m, n, a.dtype)
     return linear(a, w, skinny=True)
@@ -103,7 +128,9 @@ def linear_silu_gate(a: torch.Tensor, w_up_gate: torch.Tensor):
     m, k = a.shape
     inter = w_up_gate.shape[0] // 2
     out = torch.empty((m, inter), dtype=a.dtype, device=a.device)
-    _hip.call("swl_gemm_skinny_silu_gate", _hip.ptr(out), _hip.ptr(a), _hip.ptr(w_up_gate), m, inter, k,
+    wp = _packed_of(w_up_gate)
+    _hip.call("swl_gemm_skinny_packed_silu_gate" if wp is not None else "swl_gemm_skinny_silu_gate", _hip.ptr(out),
+              _hip.ptr(a), _hip.ptr(wp if wp is not None else w_up_gate), m, inter, k,
               _row_stride(a), inter, _hip.dtype_code(a.dtype), _hip.stream())
     return out
 

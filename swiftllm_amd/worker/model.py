@@ -38,7 +38,7 @@ from .kernels.linear import NormPending
 from .layers.pre_layer import LlamaPreLayer
 from .layers.transformer_layer import LlamaTransformerLayer
 from .layers.post_layer import LlamaPostLayer
-from .weight import load_weights
+from .weight import load_weights, pack_decode_weights
 
 _DTYPES = {"float16": torch.float16, "fp16": torch.float16, "half": torch.float16,
            "bfloat16": torch.bfloat16, "bf16": torch.bfloat16}
@@ -94,6 +94,7 @@ class LlamaModel:
         self.weight = load_weights(self.model_config, self.dtype, self.engine_config.model_path,
                                    self.engine_config.use_dummy, device=self.device,
                                    fuse_qkv=getattr(self.engine_config, "fuse_qkv", False))
+        self.repack_decode_weights()
         self._init_to_get_rotary()
         self._num_slots = torch.cuda.get_device_properties(self.device).multi_processor_count
         side_stream = torch.cuda.Stream()
@@ -105,6 +106,14 @@ class LlamaModel:
         ]
         self.post_layer = LlamaPostLayer(self.model_config, self.weight)
         self.post_layer.skinny = bool(getattr(self.engine_config, "use_skinny_gemm", False))
+
+    @torch.inference_mode()
+    def repack_decode_weights(self):
+        """(Re)build the MFMA-fragment-order copies the decode GEMMs stream (EngineConfig.pack_decode_weights). Called
+        by load_weights; call again after modifying weights in place."""
+        ecfg = self.engine_config
+        if getattr(ecfg, "pack_decode_weights", False) and getattr(ecfg, "use_skinny_gemm", False):
+            pack_decode_weights(self.weight)
 
     @torch.inference_mode()
     def profile_num_blocks(self) -> int:

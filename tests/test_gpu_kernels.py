@@ -745,3 +745,45 @@ def test_paged_attention_from_qkv_slabs_equals_three_kernels(dtype, sbs, H, KVH,
     assert torch.equal(o2.view(nd, H, D), o1)
     assert torch.equal(kc2, kc1) and torch.equal(vc2, vc1)
     assert not torch.equal(kc2.cpu(), kc)                      # the new token really went into the pool
+
+
+# ---- pre-packed weights ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [1, 7, 32])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (6144, 4096), (28672, 4096), (4096, 14336), (128, 128), (96, 384),
+                                 (160, 1152), (64, 1536), (32, 2048 + 128)])
+def test_packed_weight_gemms_equal_row_major_bits(dtype, M, N, K):
+    """W repacked in MFMA-fragment order: swl_gemm_skinny_packed / _partial / _silu_gate give the bits of their
+    row-major twins for every k-split (same MFMA order), through the operator API too."""
+    from swiftllm_amd import _hip
+    from swiftllm_amd.worker.kernels import linear as _  # noqa: F401
+    import importlib
+    L = importlib.import_module("swiftllm_amd.worker.kernels.linear")
+    g = gen(N + K + M)
+    x = torch.randn(M, K, generator=g).to(dtype).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dtype).cuda()
+    plain = L.linear(x, w, skinny=True)
+    ws = torch.empty(16 * M * N, dtype=torch.float32, device="cuda")
+    code = _hip.dtype_code(dtype)
+    wp = torch.empty_like(w)
+    _hip.call("swl_gemm_pack_weight", wp.data_ptr(), w.data_ptr(), N, K, code, _hip.stream())
+    for ks in (0, 1, 2, 4, 8, 16):
+        if ks and K % (128 * ks):
+            continue
+        a, b = torch.empty_like(plain), torch.empty_like(plain)
+        _hip.call("swl_gemm_skinny", a.data_ptr(), x.data_ptr(), w.data_ptr(), ws.data_ptr(), ws.numel() * 4, M, N, K,
+                  K, N, ks, code, _hip.stream())
+        _hip.call("swl_gemm_skinny_packed", b.data_ptr(), x.data_ptr(), wp.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                  M, N, K, K, N, ks, code, _hip.stream())
+        assert torch.equal(a, b), ks
+    # operator API: attaching the packed copy switches linear / linear_splitk / linear_silu_gate over, same bits
+    part0 = L.linear_splitk(x, w, always=True)
+    s0 = part0.materialize() if isinstance(part0, L.SplitKPartials) else part0
+    gate0 = L.linear_silu_gate(x, w) if N % 64 == 0 else None
+    L.pack_weight(w)
+    assert torch.equal(L.linear(x, w, skinny=True), plain)
+    part1 = L.linear_splitk(x, w, always=True)
+    s1 = part1.materialize() if isinstance(part1, L.SplitKPartials) else part1
+    assert torch.equal(s1, s0)
+    if gate0 is not None:
+        assert torch.equal(L.linear_silu_gate(x, w), gate0)

@@ -34,9 +34,9 @@ def _make_model(tmp_path, cfg, sd, num_blocks=24, **kw):
                                   dict(fuse_qkv=False), dict(use_skinny_gemm=False),
                                   dict(fuse_rope_kvstore=False), dict(use_hip_graph=True),
                                   dict(fuse_decode_layer=True), dict(fuse_decode_layer=True, use_hip_graph=True),
-                                  dict(fuse_rope_into_attention=False)],
+                                  dict(fuse_rope_into_attention=False), dict(pack_decode_weights=False)],
                          ids=["default", "reference_blas_calls", "unfused_qkv", "blas_gemm", "unfused_rope",
-                              "hipgraph", "fused_layer", "fused_layer_hipgraph", "rope_kernel"])
+                              "hipgraph", "fused_layer", "fused_layer_hipgraph", "rope_kernel", "row_major_weights"])
 def test_forward_matches_reference_golden(tmp_path, golden, opts):
     """The scripted run frozen from the reference (fp16, BASELINE configs[0] model)."""
     g = golden("e2e_tiny_fp16.pt")

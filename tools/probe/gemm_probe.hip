@@ -409,3 +409,177 @@ extern "C" int probe_prefetch(const void *w, long long row_pitch, int rows, int 
                        static_cast<const char *>(w), row_pitch, rows_per_wg, bytes_per_row, static_cast<int *>(sink));
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// ---- access-pattern probe: stream W with `RUN` contiguous bytes per row per instruction ------------------------
+// A wave owns 32 rows; per step it issues 16 x 16-byte-per-lane loads = 16 KiB covering [32 rows][512 B]
+// (RUN = 256: as two K-tiles of the product kernel, 4 rows x 256 B per instruction; RUN = 512: 2 rows x 512 B;
+// RUN = 1024: 1 row x 1 KiB per instruction, 16 rows per step and two steps per 32 rows).
+template <int RUN>
+__global__ __launch_bounds__(256, 2) void stream_pattern_kernel(const swl::bf16 *__restrict__ w, int N, int K, int *sink) {
+    using namespace swl;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = (blockIdx.x * 4 + wave) * 32;
+    if (n0 >= N) return;
+    constexpr int LPR = RUN / 16;          // lanes per row
+    constexpr int RPI = 64 / LPR;          // rows per instruction
+    const int r = lane / LPR, c = lane % LPR;
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 acc = {0, 0, 0, 0};
+    const char *base = reinterpret_cast<const char *>(w);
+    const long long row_bytes = static_cast<long long>(K) * 2;
+    // step = 16 instructions = 16 KiB: rows [rb, rb + 16*RPI) x RUN bytes at byte offset kb
+    const int rows_per_step = 16 * RPI;                 // 64 (256), 32 (512), 16 (1024)
+    const int steps_per_colblock = 32 / (rows_per_step > 32 ? 32 : rows_per_step); // 1, 1, 2
+    const int col_bytes = rows_per_step > 32 ? RUN * 2 : RUN; // RUN=256: two k-chunks of 256 B per step
+    for (long long kb = 0; kb < row_bytes; kb += col_bytes) {
+        for (int s = 0; s < steps_per_colblock; ++s) {
+            u4 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                int row, off;
+                if (RUN == 256) { row = (i & 7) * 4 + r; off = (i >> 3) * 256 + c * 16; }
+                else { row = s * rows_per_step + i * RPI + r; off = c * 16; }
+                v[i] = __builtin_nontemporal_load(reinterpret_cast<const u4 *>(base + (n0 + row) * row_bytes + kb + off));
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc ^= v[i];
+        }
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) *sink = 1;
+}
+
+extern "C" int probe_stream_pattern(int run, const void *w, int N, int K, void *sink, void *stream) {
+    const dim3 grid(N / 128), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const swl::bf16 *wp = static_cast<const swl::bf16 *>(w);
+    if (run == 256) hipLaunchKernelGGL(stream_pattern_kernel<256>, grid, block, 0, s, wp, N, K, static_cast<int *>(sink));
+    else if (run == 512) hipLaunchKernelGGL(stream_pattern_kernel<512>, grid, block, 0, s, wp, N, K, static_cast<int *>(sink));
+    else if (run == 1024) hipLaunchKernelGGL(stream_pattern_kernel<1024>, grid, block, 0, s, wp, N, K, static_cast<int *>(sink));
+    else return -3;
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---- candidate 3: PRE-PACKED weights ----------------------------------------------------------------------------
+// W is repacked once (at load time) into MFMA-fragment order: [N/32][K/16][64 lanes][8 elements] — the A operand of
+// v_mfma_f32_32x32x16 for 32 rows x 16 k is ONE contiguous KiB, a wave's whole K range for its 32 rows one
+// contiguous run (K*64 bytes). Loads go global -> VGPR -> MFMA: no LDS round trip for W, perfect DRAM locality.
+// x tile shared by the workgroup through LDS as in the ring kernel. D-deep register ring of 8 KiB tiles.
+template <int D, int OCC>
+__global__ __launch_bounds__(256, OCC) void packed_kernel(void *__restrict__ out_, const swl::bf16 *__restrict__ x,
+                                                          const swl::bf16 *__restrict__ wpk, int M, int N, int K,
+                                                          int kc, int64_t x_stride) {
+    using namespace swl;
+    typedef bf16 T;
+    constexpr int XL = 2;
+    __shared__ __attribute__((aligned(16))) T xs[2][32 * kKT];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col0 = (blockIdx.x * 4 + wave) * 32;
+    const bool tile_ok = col0 < N;
+    const int nt = tile_ok ? col0 / 32 : 0;
+    const int ksplit = blockIdx.y;
+    const int k_begin = ksplit * kc;
+    const int nkt = kc / kKT;
+    const int rsub = lane >> 4, chunk = lane & 15;
+    // packed source: block (nt, k16) at ((nt * K/16) + k16) * 512 elements, lane l at + l*8
+    const T *wsrc = wpk + (static_cast<int64_t>(nt) * (K / 16) + k_begin / 16) * 512 + lane * 8;
+    const T *xsrc[XL];
+    int xs_wr[XL];
+#pragma unroll
+    for (int q = 0; q < XL; ++q) {
+        const int row = 4 * (wave * XL + q) + rsub;
+        xsrc[q] = x + static_cast<int64_t>(min(row, M - 1)) * x_stride + k_begin + chunk * 8;
+        xs_wr[q] = row * kKT + ((chunk ^ (row & 15)) << 3);
+    }
+    const int l32 = lane & 31, hf = lane >> 5;
+    vec8_t<T> wr[D][8], xr[D][XL];
+    float16_t acc = float16_t{};
+#define PK_ISSUE(slot, tile)                                                                          \
+    {                                                                                                \
+        _Pragma("unroll") for (int q_ = 0; q_ < XL; ++q_) xr[slot][q_] = load8(xsrc[q_] + (tile) * kKT); \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                             \
+            wr[slot][i_] = load8_nt(wsrc + (static_cast<int64_t>(tile) * 8 + i_) * 512);             \
+    }
+#define PK_STAGE_X(slot, buf)                                                                         \
+    {                                                                                                \
+        _Pragma("unroll") for (int q_ = 0; q_ < XL; ++q_)                                            \
+            *reinterpret_cast<vec8_t<T> *>(&xs[buf][xs_wr[q_]]) = xr[slot][q_];                      \
+    }
+#define PK_PROCESS(slot, buf)                                                                         \
+    {                                                                                                \
+        _Pragma("unroll") for (int kk_ = 0; kk_ < kKT / 16; ++kk_) {                                 \
+            const int off_ = l32 * kKT + (((2 * kk_ + hf) ^ (l32 & 15)) << 3);                       \
+            const vec8_t<T> b_ = *reinterpret_cast<const vec8_t<T> *>(&xs[buf][off_]);               \
+            acc = mfma(wr[slot][kk_], b_, acc);                                                      \
+        }                                                                                            \
+    }
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d)
+        if (d < nkt) PK_ISSUE(d, d);
+    PK_STAGE_X(0, 0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 2 * D - 1 <= nkt; kt += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            PK_ISSUE((d + D - 1) % D, kt + d + D - 1);
+            PK_PROCESS(d, (kt + d) & 1);
+            PK_STAGE_X((d + 1) % D, (kt + d + 1) & 1);
+            __syncthreads();
+        }
+    }
+    const int rem = nkt - kt;
+#pragma unroll
+    for (int t = 0; t < 2 * D - 2; ++t) {
+        if (t < rem) {
+            if (t + D - 1 < rem) PK_ISSUE((t + D - 1) % D, kt + t + D - 1);
+            PK_PROCESS(t % D, (kt + t) & 1);
+            if (t + 1 < rem) {
+                PK_STAGE_X((t + 1) % D, (kt + t + 1) & 1);
+                __syncthreads();
+            }
+        }
+    }
+#undef PK_ISSUE
+#undef PK_STAGE_X
+#undef PK_PROCESS
+    if (tile_ok && l32 < M) {
+        const int n0 = col0;
+        if (gridDim.y > 1) {
+            float *slab = static_cast<float *>(out_) + (static_cast<int64_t>(ksplit) * M + l32) * N + n0 + 4 * hf;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4_t v = {acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]};
+                *reinterpret_cast<float4_t *>(slab + 8 * r4) = v;
+            }
+        } else {
+            typedef T vec4 __attribute__((ext_vector_type(4)));
+            T *o = static_cast<T *>(out_) + static_cast<int64_t>(l32) * N + n0 + 4 * hf;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                vec4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = to_t<T>(acc[4 * r4 + e]);
+                *reinterpret_cast<vec4 *>(o + 8 * r4) = v;
+            }
+        }
+    }
+}
+
+extern "C" int probe_packed(int depth, int occ, void *out, const void *x, const void *wpk, int M, int N, int K, int ks,
+                            void *stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int kc = K / ks;
+    const dim3 grid((N / 32 + 3) / 4, ks);
+#define PCASE(DD, O)                                                                                  \
+    if (depth == DD && occ == O) {                                                                    \
+        hipLaunchKernelGGL((packed_kernel<DD, O>), grid, dim3(256), 0, s, out,                        \
+                           static_cast<const swl::bf16 *>(x), static_cast<const swl::bf16 *>(wpk), M, N, K, kc, \
+                           (int64_t)K);                                                               \
+        return hipGetLastError() == hipSuccess ? 0 : -1;                                              \
+    }
+    PCASE(2, 2) PCASE(3, 2) PCASE(4, 2) PCASE(2, 3) PCASE(3, 3) PCASE(2, 4) PCASE(5, 2) PCASE(6, 1)
+#undef PCASE
+    return -3;
+}

@@ -33,6 +33,11 @@ namespace swl {
 
 constexpr int kBlk = 16;          // tokens per KV block (engine_config.block_size)
 
+template <int V>
+struct IntTag {
+    static constexpr int value = V;
+};
+
 struct PagedAttnParams {
     void *o_direct;
     const void *q;
@@ -205,30 +210,31 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
     };
 
     int b = tok_begin / kBlk + wave;
-    if constexpr (QKV) { // first: two blocks per wave are streaming while the prologue below runs
+    if constexpr (!QKV) {
         if (b < blk_end) load_block(b, Ka, Va);
-        if (b + NW < blk_end) load_block(b + NW, Kb, Vb);
     } else {
-        if (b < blk_end) load_block(b, Ka, Va);
-    }
-    if constexpr (QKV) {
+        // Prologue order matters (loads return in order within a wave): a thread first REQUESTS the slabs of its
+        // item, then its wave requests two KV blocks (16 KiB, the stream is running), and only then the item is
+        // finished — the slab data never queues behind 16 KiB of KV, and no wave delays its KV requests.
         const bool owner = tok_end == len; // the split that attends (and stores) the new token
-        constexpr int kRot = D / 16;         // rotation items per head
-        const int n_items = G * kRot + (owner ? kRot + D / 8 : 0);
+        constexpr int kRot = D / 16;       // rotation items per head
+        const int n_items = G * kRot + (owner ? kRot + D / 8 : 0); // <= one per thread
         const int64_t qkv_row = static_cast<int64_t>(p.H + 2 * p.KVH) * D;
         const int64_t slab_stride = static_cast<int64_t>(gridDim.z) * qkv_row;
         const int64_t row_off = seq * qkv_row;
-        const int64_t trow = p.pos_idx ? p.pos_idx[seq] : pos;
-        for (int item = threadIdx.x; item < n_items; item += NT) {
-            if (item < (G + 1) * kRot) {
-                const bool is_q = item < G * kRot;
-                const int c = item % kRot;
-                const int head = is_q ? kvh * G + item / kRot : p.H + kvh;
-                const vec8_t<T> cv = load8(static_cast<const T *>(p.cos_t) + trow * (D / 2) + c * 8);
-                const vec8_t<T> sv = load8(static_cast<const T *>(p.sin_t) + trow * (D / 2) + c * 8);
-                const int64_t off = row_off + static_cast<int64_t>(head) * D + c * 8;
-                vec8_t<T> x0 = load8_splitk<T>(p.qkv_slabs, p.ks, slab_stride, off);
-                vec8_t<T> x1 = load8_splitk<T>(p.qkv_slabs, p.ks, slab_stride, off + D / 2);
+        const int item = threadIdx.x;
+        const bool has = item < n_items;
+        const bool is_rot = item < (G + 1) * kRot;
+        const bool is_q = item < G * kRot;
+        const int c = is_rot ? item % kRot : item - (G + 1) * kRot;
+        const int head = is_q ? kvh * G + item / kRot : (is_rot ? p.H + kvh : p.H + p.KVH + kvh);
+        const int64_t off = row_off + static_cast<int64_t>(head) * D + c * 8;
+        auto prefetch_kv = [&]() {
+            if (b < blk_end) load_block(b, Ka, Va);
+            if (b + NW < blk_end) load_block(b + NW, Kb, Vb);
+        };
+        auto finish = [&](vec8_t<T> x0, vec8_t<T> x1, const vec8_t<T> &cv, const vec8_t<T> &sv) {
+            if (is_rot) {
                 rotate8<T>(x0, x1, cv, sv);
                 T *dst = is_q ? &sm_q[(item / kRot) * D] : &sm_kv[0];
                 *reinterpret_cast<vec8_t<T> *>(dst + c * 8) = x0;
@@ -240,14 +246,76 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
                     store8(pool + D / 2 + c * 8, x1);
                 }
             } else {
-                const int c = item - (G + 1) * kRot;
-                const vec8_t<T> vv = load8_splitk<T>(
-                    p.qkv_slabs, p.ks, slab_stride,
-                    row_off + static_cast<int64_t>(p.H + p.KVH + kvh) * D + c * 8);
-                *reinterpret_cast<vec8_t<T> *>(&sm_kv[D + c * 8]) = vv;
+                *reinterpret_cast<vec8_t<T> *>(&sm_kv[D + c * 8]) = x0;
                 T *pool = const_cast<T *>(vc) + (static_cast<int64_t>(bt[last_blk]) * blk_pitch + layer_head) *
                                                     tile_elems + (pos % kBlk) * D;
-                store8(pool + c * 8, vv);
+                store8(pool + c * 8, x0);
+            }
+        };
+        auto prologue = [&](auto ks_tag) {
+            constexpr int KS = decltype(ks_tag)::value;
+            float4_t a0[KS], b0[KS], a1[KS], b1[KS];
+            vec8_t<T> cv = {}, sv = {};
+            if (has) {
+                const float *s0 = p.qkv_slabs + off;
+#pragma unroll
+                for (int k = 0; k < KS; ++k) {
+                    a0[k] = *reinterpret_cast<const float4_t *>(s0 + k * slab_stride);
+                    b0[k] = *reinterpret_cast<const float4_t *>(s0 + k * slab_stride + 4);
+                }
+                if (is_rot) {
+                    const int64_t trow = p.pos_idx ? p.pos_idx[seq] : pos;
+                    cv = load8(static_cast<const T *>(p.cos_t) + trow * (D / 2) + c * 8);
+                    sv = load8(static_cast<const T *>(p.sin_t) + trow * (D / 2) + c * 8);
+#pragma unroll
+                    for (int k = 0; k < KS; ++k) {
+                        a1[k] = *reinterpret_cast<const float4_t *>(s0 + D / 2 + k * slab_stride);
+                        b1[k] = *reinterpret_cast<const float4_t *>(s0 + D / 2 + k * slab_stride + 4);
+                    }
+                }
+            }
+            prefetch_kv();
+            if (has) {
+                // slab order, one rounding: the bits of load8_splitk / the stand-alone reduce kernel
+                float4_t sa0 = {0.f, 0.f, 0.f, 0.f}, sb0 = sa0, sa1 = sa0, sb1 = sa0;
+#pragma unroll
+                for (int k = 0; k < KS; ++k) {
+                    sa0 += a0[k];
+                    sb0 += b0[k];
+                }
+                if (is_rot) {
+#pragma unroll
+                    for (int k = 0; k < KS; ++k) {
+                        sa1 += a1[k];
+                        sb1 += b1[k];
+                    }
+                }
+                vec8_t<T> x0, x1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x0[e] = static_cast<T>(sa0[e]);
+                    x0[4 + e] = static_cast<T>(sb0[e]);
+                    x1[e] = static_cast<T>(sa1[e]);
+                    x1[4 + e] = static_cast<T>(sb1[e]);
+                }
+                finish(x0, x1, cv, sv);
+            }
+        };
+        if (p.ks == 4) prologue(IntTag<4>{});
+        else if (p.ks == 2) prologue(IntTag<2>{});
+        else if (p.ks == 1) prologue(IntTag<1>{});
+        else { // many slabs: too many registers to hold them raw — KV first, then the summing loads
+            prefetch_kv();
+            if (has) {
+                vec8_t<T> cv = {}, sv = {}, x1 = {};
+                vec8_t<T> x0 = load8_splitk<T>(p.qkv_slabs, p.ks, slab_stride, off);
+                if (is_rot) {
+                    const int64_t trow = p.pos_idx ? p.pos_idx[seq] : pos;
+                    cv = load8(static_cast<const T *>(p.cos_t) + trow * (D / 2) + c * 8);
+                    sv = load8(static_cast<const T *>(p.sin_t) + trow * (D / 2) + c * 8);
+                    x1 = load8_splitk<T>(p.qkv_slabs, p.ks, slab_stride, off + D / 2);
+                }
+                finish(x0, x1, cv, sv);
             }
         }
         __syncthreads();

@@ -26,6 +26,11 @@ class LlamaPostLayer:
                              device=input_embds.device, dtype=torch.int32)))
         last_input = input_embds.index_select(0, idx)    # fresh [batch, hidden] copy
         rmsnorm_inplace(last_input, self.weights.final_norm, self.model_config.rms_norm_eps)
+        return self.forward_normed(last_input)
+
+    def forward_normed(self, last_input: torch.Tensor) -> torch.Tensor:
+        """lm_head + greedy sampling on rows that already went through the final norm (a pure-decode batch whose
+        last add + norm ran fused on the split-K partials of the last down projection: every row is a last token)."""
         logits = linear(last_input, self.weights.lm_head, self.skinny)   # [batch, vocab]
         if self.logits_tap is not None:
             self.logits_tap.append(logits)

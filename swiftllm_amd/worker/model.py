@@ -35,6 +35,7 @@ from .block_manager import BlockManager
 from .infer_state import LlamaInferState
 from .kernels.block_swapping import swap_blocks
 from .kernels.linear import NormPending
+from .kernels.rmsnorm import fused_add_rmsnorm_from_splitk
 from .layers.pre_layer import LlamaPreLayer
 from .layers.transformer_layer import LlamaTransformerLayer
 from .layers.post_layer import LlamaPostLayer
@@ -250,6 +251,10 @@ class LlamaModel:
         if isinstance(x, NormPending):          # fused decode layers: the stream already holds x + residual
             return self.post_layer.forward(x.residual, infer_state)
         if not isinstance(x, torch.Tensor):     # the last down projection left as split-K partials
+            if infer_state.num_prefill_seqs == 0:
+                # pure decode: every row is a last token — reduce + residual add + final norm in one launch
+                x = fused_add_rmsnorm_from_splitk(x, residual, self.weight.final_norm, self.model_config.rms_norm_eps)
+                return self.post_layer.forward_normed(x)
             x = x.materialize()
         x += residual
         return self.post_layer.forward(x, infer_state)

@@ -227,12 +227,13 @@ def gemm_roofline(model, batch, iters):
     alg_bytes = 2 * I * K * e + M * K * e + M * I * e
     gbs = alg_bytes / (us * 1e-6) / 1e9
     traffic, src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r01e_gemm_silu_pmc.json")
+    pmc_name = "r01f_gemm_silu_packed_pmc.json" if packed else "r01e_gemm_silu_pmc.json"
+    pmc_path = os.path.join(ROOT, "profiles", pmc_name)
     if os.path.exists(pmc_path) and (I, K) == (14336, 4096) and model.dtype == torch.bfloat16:
         with open(pmc_path, encoding="utf-8") as f:
             pmc = json.load(f)
         traffic = int(alg_bytes * pmc["traffic_over_algorithmic"])
-        src = "profiles/r01e_gemm_silu_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, scaled by bytes)"
+        src = f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, scaled by bytes)"
     return dict(bound="hbm", kernel="gemm_skinny_ring_kernel<SiluGate%s> (up/gate projection + SiLU-gate)" % (", packed W" if packed else ""),
                 achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
                 frac_of_measured_copy=round(gbs / HBM_COPY_GBS, 4), traffic=traffic, traffic_source=src,

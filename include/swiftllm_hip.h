@@ -254,6 +254,12 @@ int swl_gemm_skinny_packed_partial(float *slabs, size_t slabs_bytes, const void 
 int swl_gemm_skinny_packed_silu_gate(void *out, const void *x, const void *w_up_gate_packed, int32_t M, int32_t I,
                                      int32_t K, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype,
                                      swl_stream_t stream);
+/* Medium batches on a packed weight: out[M, N] = x . W^T for 32 < M <= 128 tokens (valid for any M <= 128); 2 or 4
+ * blocks of 32 tokens share every weight fragment. workspace >= k_splits * M * N * 4 bytes when K is split
+ * (k_splits = 0: library's choice; 16 * M * N * 4 bytes cover any). */
+int swl_gemm_packed_mid(void *out, const void *x, const void *w_packed, void *workspace, size_t workspace_bytes,
+                        int32_t M, int32_t N, int32_t K, int64_t x_row_stride, int64_t out_row_stride,
+                        int32_t k_splits, int32_t dtype, swl_stream_t stream);
 
 /* ---- Fused decode layer: the latency-bound hand-offs between the projections folded into the GEMMs --------
  * (reference: transformer_layer.py:31-130 runs fused_add_rmsnorm / rotary / store_kvcache as separate

@@ -993,3 +993,192 @@ extern "C" int swl_gemm_skinny_packed_silu_gate(void *out, const void *x, const 
     });
     return swl::check_launch();
 }
+
+// ---- medium batches on packed weights: 32 < M <= 128 -----------------------------------------------------------
+// With W arriving in fragment order there is no LDS traffic for W at all, so MT = 2 or 4 blocks of 32 tokens can
+// share every W fragment at the price of MT x-fragment reads per k-step (1 LDS read per MFMA; the row-major attempt
+// paid 1 + MT reads plus the W round trip and was LDS bound: profiles/r01e_gemm_mtile_experiment.jsonl). hipBLASLt
+// streams these shapes at 1.3-4.7 TB/s (profiles/r01e_hipblaslt_m48_256.jsonl).
+namespace swl {
+
+template <typename T, int MT, bool PARTIAL>
+__global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_packed_mt_kernel(
+    void *__restrict__ out_, const T *__restrict__ x, const T *__restrict__ wpk, int M, int N, int K, int kc,
+    int64_t x_stride, int64_t out_stride) {
+    constexpr int D = kRing;
+    constexpr int XL = MT * 8 / kGemmWaves; // x row-groups (4 rows each) a wave stages per tile
+    constexpr int kXTile = MT * 32 * kKT;
+    __shared__ __attribute__((aligned(16))) T xs[2 * kXTile]; // double-buffered [32*MT][128] x tile (<= 64 KiB)
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col0 = (blockIdx.x * kGemmWaves + wave) * 32;
+    const bool tile_ok = col0 < N;
+    const int nt = tile_ok ? col0 / 32 : 0;
+    const int ksplit = blockIdx.y;
+    const int k_begin = ksplit * kc;
+    const int nkt = kc / kKT;
+    const int rsub = lane >> 4, chunk = lane & 15;
+    const T *wsrc = wpk + (static_cast<int64_t>(nt) * (K / 16) + k_begin / 16) * 512 + lane * 8;
+    const T *xsrc[XL];
+    int xs_wr[XL];
+#pragma unroll
+    for (int q = 0; q < XL; ++q) {
+        const int row = 4 * (wave * XL + q) + rsub;
+        xsrc[q] = x + static_cast<int64_t>(min(row, M - 1)) * x_stride + k_begin + chunk * 8;
+        xs_wr[q] = row * kKT + ((chunk ^ (row & 15)) << 3);
+    }
+    const int l32 = lane & 31, hf = lane >> 5;
+
+    vec8_t<T> wr[D][8], xr[XL];
+    float16_t acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = float16_t{};
+    // x one tile ahead, requested BEFORE that step's W request (loads return in order: staging it at the end of the
+    // step waits for nothing younger than itself); W D-1 tiles ahead
+#define SWL_MT_ISSUE_W(slot, tile)                                                                    \
+    {                                                                                                \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                             \
+            wr[slot][i_] = load8_nt(wsrc + (static_cast<int64_t>(tile) * 8 + i_) * 512);              \
+    }
+#define SWL_MT_ISSUE_X(tile)                                                                          \
+    {                                                                                                \
+        _Pragma("unroll") for (int q_ = 0; q_ < XL; ++q_) xr[q_] = load8(xsrc[q_] + (tile) * kKT);   \
+    }
+#define SWL_MT_STAGE_X(buf)                                                                           \
+    {                                                                                                \
+        _Pragma("unroll") for (int q_ = 0; q_ < XL; ++q_)                                            \
+            *reinterpret_cast<vec8_t<T> *>(xs + (buf) * kXTile + xs_wr[q_]) = xr[q_];                \
+    }
+#define SWL_MT_PROCESS(slot, buf)                                                                     \
+    {                                                                                                \
+        const T *xl_ = xs + (buf) * kXTile;                                                          \
+        _Pragma("unroll") for (int kk_ = 0; kk_ < kKT / 16; ++kk_) {                                 \
+            const int off_ = l32 * kKT + (((2 * kk_ + hf) ^ (l32 & 15)) << 3);                       \
+            _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) {                                   \
+                const vec8_t<T> b_ = *reinterpret_cast<const vec8_t<T> *>(xl_ + mt_ * 32 * kKT + off_); \
+                acc[mt_] = mfma32x32x16(wr[slot][kk_], b_, acc[mt_]);                                \
+            }                                                                                        \
+        }                                                                                            \
+    }
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d)
+        if (d < nkt) SWL_MT_ISSUE_W(d, d);
+    SWL_MT_ISSUE_X(0);
+    SWL_MT_STAGE_X(0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 2 * D - 1 <= nkt; kt += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            SWL_MT_ISSUE_X(kt + d + 1);
+            SWL_MT_ISSUE_W((d + D - 1) % D, kt + d + D - 1);
+            SWL_MT_PROCESS(d, (kt + d) & 1);
+            SWL_MT_STAGE_X((kt + d + 1) & 1);
+            __syncthreads();
+        }
+    }
+    const int rem = nkt - kt;
+#pragma unroll
+    for (int t = 0; t < 2 * D - 2; ++t) {
+        if (t < rem) {
+            if (t + 1 < rem) SWL_MT_ISSUE_X(kt + t + 1);
+            if (t + D - 1 < rem) SWL_MT_ISSUE_W((t + D - 1) % D, kt + t + D - 1);
+            SWL_MT_PROCESS(t % D, (kt + t) & 1);
+            if (t + 1 < rem) {
+                SWL_MT_STAGE_X((kt + t + 1) & 1);
+                __syncthreads();
+            }
+        }
+    }
+#undef SWL_MT_ISSUE_W
+#undef SWL_MT_ISSUE_X
+#undef SWL_MT_STAGE_X
+#undef SWL_MT_PROCESS
+    if (!tile_ok) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = 32 * mt + l32;
+        if (m >= M) continue;
+        const int n = col0 + 4 * hf;
+        if constexpr (PARTIAL) {
+            float *slab = static_cast<float *>(out_) + (static_cast<int64_t>(ksplit) * M + m) * N + n;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4_t v = {acc[mt][4 * r4], acc[mt][4 * r4 + 1], acc[mt][4 * r4 + 2], acc[mt][4 * r4 + 3]};
+                *reinterpret_cast<float4_t *>(slab + 8 * r4) = v;
+            }
+        } else {
+            typedef T vec4 __attribute__((ext_vector_type(4)));
+            T *o = static_cast<T *>(out_) + static_cast<int64_t>(m) * out_stride + n;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                vec4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = to_t<T>(acc[mt][4 * r4 + e]);
+                *reinterpret_cast<vec4 *>(o + 8 * r4) = v;
+            }
+        }
+    }
+}
+
+// Splits as for M <= 32 (>= 768 waves), capped so the slab traffic (2 * ks * M * N * 4 B) stays under a third of
+// the weight bytes: ks <= K / (12 * M) (measured optimum at M = 48..128: o_proj 4, down_proj 8).
+static int choose_k_splits_mt(int M, int N, int K) {
+    const int tiles = N / 32;
+    const int cap = K / (12 * M);
+    int ks = 1;
+    while (ks < 16 && ks * 2 <= cap && tiles * ks < 768 && K % (kKT * ks * 2) == 0 && K / (ks * 2) >= 2 * kKT) ks *= 2;
+    return ks;
+}
+
+template <typename T>
+static int run_gemm_packed_mt(T *out, const T *x, const T *wp, float *ws, size_t ws_bytes, int M, int N, int K,
+                              int64_t xs, int64_t os, int ks, hipStream_t stream) {
+    if (ks <= 0) ks = choose_k_splits_mt(M, N, K);
+    if (K % (kKT * ks) != 0) return SWL_ERR_UNSUPPORTED;
+    const dim3 grid((N / 32 + kGemmWaves - 1) / kGemmWaves, ks), block(kGemmWaves * 64);
+    const int kc = K / ks;
+    if (ks == 1) {
+        if (M <= 64)
+            hipLaunchKernelGGL((gemm_packed_mt_kernel<T, 2, false>), grid, block, 0, stream, out, x, wp, M, N, K, kc, xs, os);
+        else
+            hipLaunchKernelGGL((gemm_packed_mt_kernel<T, 4, false>), grid, block, 0, stream, out, x, wp, M, N, K, kc, xs, os);
+        return check_launch();
+    }
+    if (!ws || ws_bytes < static_cast<size_t>(ks) * M * N * sizeof(float)) return SWL_ERR_BAD_ARG;
+    const int64_t n64 = N;
+    if (M <= 64)
+        hipLaunchKernelGGL((gemm_packed_mt_kernel<T, 2, true>), grid, block, 0, stream, ws, x, wp, M, N, K, kc, xs, n64);
+    else
+        hipLaunchKernelGGL((gemm_packed_mt_kernel<T, 4, true>), grid, block, 0, stream, ws, x, wp, M, N, K, kc, xs, n64);
+    const int64_t items = static_cast<int64_t>(M) * (N / 4);
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(static_cast<unsigned>((items + 255) / 256)), dim3(256), 0,
+                       stream, out, ws, M, N, ks, os);
+    return check_launch();
+}
+
+} // namespace swl
+
+/* out[M, N] = x . W^T for 32 < M <= 128 tokens (any M <= 128 is valid) on a weight packed by swl_gemm_pack_weight.
+ * N % 32 == 0, K % 128 == 0. workspace >= k_splits * M * N * 4 bytes when K is split (k_splits = 0: library's
+ * choice; 16 * M * N * 4 bytes cover any). */
+extern "C" int swl_gemm_packed_mid(void *out, const void *x, const void *w_packed, void *workspace,
+                                   size_t workspace_bytes, int32_t M, int32_t N, int32_t K, int64_t x_row_stride,
+                                   int64_t out_row_stride, int32_t k_splits, int32_t dtype, swl_stream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
+    if (M == 0) return SWL_OK;
+    if (!out || !x || !w_packed) return SWL_ERR_BAD_ARG;
+    if (M > 128 || (N & 31) || (K & (swl::kKT - 1))) return SWL_ERR_UNSUPPORTED;
+    if (x_row_stride < K || out_row_stride < N || (x_row_stride & 7) || (out_row_stride & 3)) return SWL_ERR_BAD_ARG;
+    if (!swl::aligned16(x) || !swl::aligned16(w_packed) || (reinterpret_cast<uintptr_t>(out) & 7u) ||
+        (workspace && !swl::aligned16(workspace)))
+        return SWL_ERR_BAD_ARG;
+    if (k_splits < 0 || k_splits > 16 || (k_splits & (k_splits - 1))) return SWL_ERR_BAD_ARG;
+    SWL_DISPATCH_DTYPE(dtype, T, {
+        return swl::run_gemm_packed_mt<T>(static_cast<T *>(out), static_cast<const T *>(x),
+                                          static_cast<const T *>(w_packed), static_cast<float *>(workspace),
+                                          workspace_bytes, M, N, K, x_row_stride, out_row_stride, k_splits,
+                                          static_cast<hipStream_t>(stream));
+    });
+}

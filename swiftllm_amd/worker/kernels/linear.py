@@ -84,8 +84,31 @@ class SplitKPartials:
         return out
 
 
+_MID_MAX_M = 128
+
+
+def _mid_ok(a: torch.Tensor, w: torch.Tensor) -> bool:
+    """Medium decode batches (32 < M <= 128) on a packed weight: 2 or 4 blocks of 32 tokens share every weight
+    fragment (swl_gemm_packed_mid). Measured against hipBLASLt (tools/gemm_micro.py --m 48/64/128): 20-30 % faster
+    over a layer up to M = 64; above that only where K >> N (down_proj: 38 vs 75 us), so the others stay on BLAS."""
+    m = a.shape[0] if a.dim() == 2 else 0
+    if not (_SKINNY_MAX_M < m <= _MID_MAX_M) or _packed_of(w) is None:
+        return False
+    n, k = w.shape
+    return (a.is_cuda and a.dtype == w.dtype and a.stride(1) == 1 and a.stride(0) % 8 == 0
+            and (m <= 64 or k >= 2 * n))
+
+
 def linear(a: torch.Tensor, w: torch.Tensor, skinny: bool = False) -> torch.Tensor:
     """a[T, in] @ w[out, in]^T -> [T, out] (fp32 accumulation, one rounding)."""
+    if skinny and _mid_ok(a, w):
+        m, k = a.shape
+        n = w.shape[0]
+        out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+        ws = _workspace(a.device, min(16, max(1, k // (12 * m))) * m * n * 4)     # the library's split cap
+        _hip.call("swl_gemm_packed_mid", _hip.ptr(out), _hip.ptr(a), _hip.ptr(_packed_of(w)), _hip.ptr(ws),
+                  ws.numel() * 4, m, n, k, _row_stride(a), n, 0, _hip.dtype_code(a.dtype), _hip.stream())
+        return out
     if skinny and _skinny_ok(a, w):
         m, k = a.shape
         n = w.shape[0]

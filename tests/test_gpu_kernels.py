@@ -787,3 +787,29 @@ def test_packed_weight_gemms_equal_row_major_bits(dtype, M, N, K):
     assert torch.equal(s1, s0)
     if gate0 is not None:
         assert torch.equal(L.linear_silu_gate(x, w), gate0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [33, 64, 65, 100, 128, 7])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (6144, 4096), (28672, 4096), (4096, 14336), (32, 128), (160, 256),
+                                 (96, 384), (64, 1152), (448, 1024)])
+def test_gemm_packed_mid_vs_fp32_reference(dtype, M, N, K):
+    """Medium-batch GEMM on packed weights (2 / 4 token blocks per weight fragment): one rounding of an
+    fp32-accumulated product for the library's split choice and forced ones; ragged workgroups, odd tile counts."""
+    from swiftllm_amd import _hip
+    g = gen(N + K + M)
+    x = torch.randn(M, K, generator=g).to(dtype).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dtype).cuda()
+    ref = x.float() @ w.float().T
+    eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    code = _hip.dtype_code(dtype)
+    wp = torch.empty_like(w)
+    _hip.call("swl_gemm_pack_weight", wp.data_ptr(), w.data_ptr(), N, K, code, _hip.stream())
+    ws = torch.empty(16 * M * N, dtype=torch.float32, device="cuda")
+    for ks in (0, 1, 2, 4, 8):
+        if ks and K % (128 * ks):
+            continue
+        out = torch.full((M, N), float("nan"), dtype=dtype, device="cuda")
+        _hip.call("swl_gemm_packed_mid", out.data_ptr(), x.data_ptr(), wp.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                  M, N, K, K, N, ks, code, _hip.stream())
+        assert ((out.float() - ref).abs() <= eps * ref.abs() + 1e-3 * eps * (K ** 0.5)).all(), ks

@@ -264,8 +264,9 @@ def test_streaming_weight_loader_equals_per_tensor_loader(tmp_path):
             assert torch.equal(getattr(la, attr), getattr(lb, attr))
 
 
-@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
-def test_full_width_layers_fast_path_equals_reference_op_sequence(tmp_path, dtype):
+@pytest.mark.parametrize("dtype,copies", [("float16", 4), ("bfloat16", 4), ("bfloat16", 6)],
+                         ids=["float16-batch32", "bfloat16-batch32", "bfloat16-batch48"])
+def test_full_width_layers_fast_path_equals_reference_op_sequence(tmp_path, dtype, copies):
     """Llama-3-8B layer geometry (hidden 4096, 32/8 heads of 128, FFN 14336; 2 layers, 8k vocabulary so the CPU
     side stays small): here every decode projection really splits K (4-8 slabs), runs the ring kernel, the
     split-K consumers and the attention kernel fed by qkv slabs — none of which the small test models reach. The
@@ -278,9 +279,9 @@ def test_full_width_layers_fast_path_equals_reference_op_sequence(tmp_path, dtyp
     tdtype = torch.float16 if dtype == "float16" else torch.bfloat16
     sd = synth.make_state_dict(cfg, seed=31, dtype=tdtype)
     g = torch.Generator().manual_seed(8)
-    lens = [1, 15, 16, 17, 100, 257, 640, 33] * 4                 # batch 32, ragged
+    lens = [1, 15, 16, 17, 100, 257, 640, 33] * copies            # batch 32 (one token block) or 48 (medium-batch GEMM), ragged
     prompts = [torch.randint(0, cfg["vocab_size"], (n,), generator=g).tolist() for n in lens]
-    base = dict(max_blocks_per_seq=64, max_tokens_in_batch=8192, max_batch_size=32, max_seqs_in_block_table=32,
+    base = dict(max_blocks_per_seq=64, max_tokens_in_batch=8192, max_batch_size=48, max_seqs_in_block_table=48,
                 dtype=dtype)
     from swiftllm_amd import LlamaModel
     synth.write_model_dir(str(tmp_path), cfg, sd)
@@ -292,7 +293,7 @@ def test_full_width_layers_fast_path_equals_reference_op_sequence(tmp_path, dtyp
         near-tie must not make the later steps incomparable)"""
         model = LlamaModel(_engine_config(str(tmp_path), **base, **opts))
         model.load_weights()
-        model.init_kvcache_and_swap(32 * 48)
+        model.init_kvcache_and_swap(48 * 48)
         model.post_layer.logits_tap = []
         tap = model.post_layer.logits_tap
         toks = [model.forward(prompts, seq_ids, [])]

@@ -37,7 +37,7 @@ def main():
     code = _hip.dtype_code(dtype)
     for name in a.shapes.split(","):
         N, K = SHAPES[name]
-        copies = max(2, min(16, int(2e9 // (N * K * 2))))
+        copies = max(2, min(16 if a.m <= 32 else 8, int(2e9 // (N * K * 2))))
         ws = [torch.empty(N, K, dtype=dtype, device="cuda").normal_(0, 0.02) for _ in range(copies)]
         x = torch.randn(a.m, K, device="cuda").to(dtype)
         out = torch.empty(a.m, N, dtype=dtype, device="cuda")
@@ -45,6 +45,21 @@ def main():
         t = bench(lambda i: torch.nn.functional.linear(x, ws[i % copies]), a.iters)
         res["blas_us"] = round(t, 2); res["blas_TBps"] = round(N * K * 2 / t / 1e6, 2)
         wsp = torch.empty(16 * a.m * N, dtype=torch.float32, device="cuda")
+        if a.m > 32:
+            wps = []
+            for w_ in ws:
+                wp_ = torch.empty_like(w_)
+                _hip.call("swl_gemm_pack_weight", wp_.data_ptr(), w_.data_ptr(), N, K, code, _hip.stream())
+                wps.append(wp_)
+            for ks in (0, 1, 2, 4, 8):
+                if ks and K % (128 * ks):
+                    continue
+                def run_mid(i, ks=ks):
+                    _hip.call("swl_gemm_packed_mid", out.data_ptr(), x.data_ptr(), wps[i % copies].data_ptr(), wsp.data_ptr(),
+                              wsp.numel() * 4, a.m, N, K, K, N, ks, code, _hip.stream())
+                t = bench(run_mid, a.iters)
+                res[f"pmid_ks{ks}_us"] = round(t, 2); res[f"pmid_ks{ks}_TBps"] = round(N * K * 2 / t / 1e6, 2)
+            del wps
         for ks in (0, 1, 2, 4, 8, 16):
             if a.m > 32:
                 break

@@ -260,6 +260,11 @@ int swl_gemm_skinny_packed_silu_gate(void *out, const void *x, const void *w_up_
 int swl_gemm_packed_mid(void *out, const void *x, const void *w_packed, void *workspace, size_t workspace_bytes,
                         int32_t M, int32_t N, int32_t K, int64_t x_row_stride, int64_t out_row_stride,
                         int32_t k_splits, int32_t dtype, swl_stream_t stream);
+int swl_gemm_packed_mid_choose_splits(int32_t M, int32_t N, int32_t K); /* its choice for k_splits = 0 */
+/* ... stopping at the fp32 partial slabs [k_splits][M][N] (k_splits >= 1) for the split-K consumers */
+int swl_gemm_packed_mid_partial(float *slabs, size_t slabs_bytes, const void *x, const void *w_packed, int32_t M,
+                                int32_t N, int32_t K, int64_t x_row_stride, int32_t k_splits, int32_t dtype,
+                                swl_stream_t stream);
 
 /* ---- Fused decode layer: the latency-bound hand-offs between the projections folded into the GEMMs --------
  * (reference: transformer_layer.py:31-130 runs fused_add_rmsnorm / rotary / store_kvcache as separate

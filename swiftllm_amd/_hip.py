@@ -58,6 +58,7 @@ SIGNATURES = {
     "swl_gemm_skinny": [_P, _P, _P, _P, ctypes.c_size_t, _I32, _I32, _I32, _I64, _I64, _I32, _I32, _P],
     "swl_gemm_pack_weight": [_P, _P, _I32, _I32, _I32, _P],
     "swl_gemm_skinny_packed": [_P, _P, _P, _P, ctypes.c_size_t, _I32, _I32, _I32, _I64, _I64, _I32, _I32, _P],
+    "swl_gemm_packed_mid_partial": [_P, ctypes.c_size_t, _P, _P, _I32, _I32, _I32, _I64, _I32, _I32, _P],
     "swl_gemm_packed_mid": [_P, _P, _P, _P, ctypes.c_size_t, _I32, _I32, _I32, _I64, _I64, _I32, _I32, _P],
     "swl_gemm_skinny_packed_partial": [_P, ctypes.c_size_t, _P, _P, _I32, _I32, _I32, _I64, _I32, _I32, _P],
     "swl_gemm_skinny_packed_silu_gate": [_P, _P, _P, _I32, _I32, _I32, _I64, _I64, _I32, _P],
@@ -81,6 +82,7 @@ _SPECIAL = {
     "swl_argmax_scratch_bytes": ([_I64], ctypes.c_size_t),
     "swl_gemm_skinny_workspace_bytes": ([_I32, _I32, _I32], ctypes.c_size_t),
     "swl_gemm_skinny_choose_splits": ([_I32, _I32], _I32),
+    "swl_gemm_packed_mid_choose_splits": ([_I32, _I32, _I32], _I32),
 }
 
 _lock = threading.Lock()

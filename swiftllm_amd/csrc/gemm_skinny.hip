@@ -1132,14 +1132,15 @@ static int choose_k_splits_mt(int M, int N, int K) {
     return ks;
 }
 
+// reduce == false: stop after the partial slabs (ks >= 1) for a fused consumer
 template <typename T>
 static int run_gemm_packed_mt(T *out, const T *x, const T *wp, float *ws, size_t ws_bytes, int M, int N, int K,
-                              int64_t xs, int64_t os, int ks, hipStream_t stream) {
+                              int64_t xs, int64_t os, int ks, hipStream_t stream, bool reduce = true) {
     if (ks <= 0) ks = choose_k_splits_mt(M, N, K);
     if (K % (kKT * ks) != 0) return SWL_ERR_UNSUPPORTED;
     const dim3 grid((N / 32 + kGemmWaves - 1) / kGemmWaves, ks), block(kGemmWaves * 64);
     const int kc = K / ks;
-    if (ks == 1) {
+    if (ks == 1 && reduce) {
         if (M <= 64)
             hipLaunchKernelGGL((gemm_packed_mt_kernel<T, 2, false>), grid, block, 0, stream, out, x, wp, M, N, K, kc, xs, os);
         else
@@ -1152,6 +1153,7 @@ static int run_gemm_packed_mt(T *out, const T *x, const T *wp, float *ws, size_t
         hipLaunchKernelGGL((gemm_packed_mt_kernel<T, 2, true>), grid, block, 0, stream, ws, x, wp, M, N, K, kc, xs, n64);
     else
         hipLaunchKernelGGL((gemm_packed_mt_kernel<T, 4, true>), grid, block, 0, stream, ws, x, wp, M, N, K, kc, xs, n64);
+    if (!reduce) return check_launch();
     const int64_t items = static_cast<int64_t>(M) * (N / 4);
     hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(static_cast<unsigned>((items + 255) / 256)), dim3(256), 0,
                        stream, out, ws, M, N, ks, os);
@@ -1180,5 +1182,31 @@ extern "C" int swl_gemm_packed_mid(void *out, const void *x, const void *w_packe
                                           static_cast<const T *>(w_packed), static_cast<float *>(workspace),
                                           workspace_bytes, M, N, K, x_row_stride, out_row_stride, k_splits,
                                           static_cast<hipStream_t>(stream));
+    });
+}
+
+/* The split count swl_gemm_packed_mid picks for k_splits = 0 (0 = shape unsupported). */
+extern "C" int swl_gemm_packed_mid_choose_splits(int32_t M, int32_t N, int32_t K) {
+    if (M <= 0 || M > 128 || N <= 0 || K <= 0 || (N & 31) || (K & (swl::kKT - 1))) return 0;
+    return swl::choose_k_splits_mt(M, N, K);
+}
+
+/* Partial slabs only (slabs[k_splits][M][N] fp32, k_splits >= 1) for the split-K consumers (swl_splitk_*,
+ * swl_paged_attn_decode_qkv). */
+extern "C" int swl_gemm_packed_mid_partial(float *slabs, size_t slabs_bytes, const void *x, const void *w_packed,
+                                           int32_t M, int32_t N, int32_t K, int64_t x_row_stride, int32_t k_splits,
+                                           int32_t dtype, swl_stream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
+    if (M == 0) return SWL_OK;
+    if (!slabs || !x || !w_packed || k_splits < 1 || k_splits > 16 || (k_splits & (k_splits - 1)))
+        return SWL_ERR_BAD_ARG;
+    if (M > 128 || (N & 31) || (K & (swl::kKT - 1))) return SWL_ERR_UNSUPPORTED;
+    if (x_row_stride < K || (x_row_stride & 7) || !swl::aligned16(x) || !swl::aligned16(w_packed) ||
+        !swl::aligned16(slabs))
+        return SWL_ERR_BAD_ARG;
+    SWL_DISPATCH_DTYPE(dtype, T, {
+        return swl::run_gemm_packed_mt<T>(static_cast<T *>(nullptr), static_cast<const T *>(x),
+                                          static_cast<const T *>(w_packed), slabs, slabs_bytes, M, N, K, x_row_stride, N,
+                                          k_splits, static_cast<hipStream_t>(stream), false);
     });
 }

@@ -22,11 +22,17 @@ _SKINNY_MAX_M = 32
 _workspaces = {}    # device -> persistent fp32 split-K scratch (fixed address: hipGraph replays use it)
 
 
+_retired = []       # outgrown workspaces stay allocated: captured hipGraphs may still replay against them
+
+
 def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
     ws = _workspaces.get(device)
     if ws is None or ws.numel() * 4 < nbytes:
-        # sized once for the widest split projection a LLaMA has (fused qkv / o / down: N <= 16384)
-        ws = torch.empty(max(nbytes, 16 * _SKINNY_MAX_M * 16384 * 4) // 4, dtype=torch.float32, device=device)
+        if ws is not None:
+            _retired.append(ws)
+        # sized once for the widest split projection a LLaMA has (fused qkv / o / down: N <= 16384, <= 16 slabs of 32
+        # tokens, or the medium-batch equivalent): 64 MiB
+        ws = torch.empty(max(nbytes, 64 << 20) // 4, dtype=torch.float32, device=device)
         _workspaces[device] = ws
     return ws
 
@@ -105,9 +111,10 @@ def linear(a: torch.Tensor, w: torch.Tensor, skinny: bool = False) -> torch.Tens
         m, k = a.shape
         n = w.shape[0]
         out = torch.empty((m, n), dtype=a.dtype, device=a.device)
-        ws = _workspace(a.device, min(16, max(1, k // (12 * m))) * m * n * 4)     # the library's split cap
+        ks = _hip.load().swl_gemm_packed_mid_choose_splits(m, n, k)
+        ws = _workspace(a.device, ks * m * n * 4 if ks > 1 else 0)
         _hip.call("swl_gemm_packed_mid", _hip.ptr(out), _hip.ptr(a), _hip.ptr(_packed_of(w)), _hip.ptr(ws),
-                  ws.numel() * 4, m, n, k, _row_stride(a), n, 0, _hip.dtype_code(a.dtype), _hip.stream())
+                  ws.numel() * 4, m, n, k, _row_stride(a), n, ks, _hip.dtype_code(a.dtype), _hip.stream())
         return out
     if skinny and _skinny_ok(a, w):
         m, k = a.shape
@@ -128,6 +135,16 @@ def linear_splitk(a: torch.Tensor, w: torch.Tensor, always: bool = False):
     """Like linear(a, w, skinny=True) but returns SplitKPartials when the kernel splits K (the caller
     hands them to a fused consumer); falls through to `linear` otherwise. `always`: also return the
     partial form (a single fp32 slab) when K is not split — for consumers that only take slabs."""
+    if _mid_ok(a, w) and a.shape[0] <= 64:      # medium batch on a packed weight: same contract, own kernel
+        m, k = a.shape
+        n = w.shape[0]
+        ks = _hip.load().swl_gemm_packed_mid_choose_splits(m, n, k)
+        if ks > 1 or (always and ks == 1):
+            ws = _workspace(a.device, ks * m * n * 4)
+            _hip.call("swl_gemm_packed_mid_partial", _hip.ptr(ws), ws.numel() * 4, _hip.ptr(a), _hip.ptr(_packed_of(w)),
+                      m, n, k, _row_stride(a), ks, _hip.dtype_code(a.dtype), _hip.stream())
+            return SplitKPartials(ws, ks, m, n, a.dtype)
+        return linear(a, w, skinny=True)
     if _skinny_ok(a, w):
         m, k = a.shape
         n = w.shape[0]

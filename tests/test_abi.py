@@ -73,3 +73,24 @@ def test_argument_validation_without_a_gpu():
     assert lib.swl_rmsnorm(p, p, 1e-5, 1, 8, 7, None) == -1     # unknown dtype code
     with pytest.raises(_hip.HipLibraryError):
         _hip.call("swl_silu_mul", None, 4, 7, _hip.SWL_F16, None)   # I % 8 != 0
+
+
+def test_split_heuristics_are_host_side_and_stable():
+    """K-split choices are pure host arithmetic (observable without a GPU); the values are the measured optima
+    recorded in DESIGN.md section 4.3 / 5.1 for the Llama-3-8B projections."""
+    lib = _hip.load()
+    assert lib.swl_gemm_skinny_choose_splits(6144, 4096) == 4        # fused qkv
+    assert lib.swl_gemm_skinny_choose_splits(4096, 4096) == 8        # o_proj
+    assert lib.swl_gemm_skinny_choose_splits(4096, 14336) == 8       # down_proj
+    assert lib.swl_gemm_skinny_choose_splits(28672, 4096) == 1       # up/gate: enough tiles already
+    assert lib.swl_gemm_skinny_choose_splits(128256, 4096) == 1      # lm_head
+    assert lib.swl_gemm_skinny_choose_splits(100, 4096) == 0         # N % 32 != 0: unsupported
+    assert lib.swl_gemm_packed_mid_choose_splits(64, 4096, 4096) == 4     # slab traffic capped at K / (12 M)
+    assert lib.swl_gemm_packed_mid_choose_splits(64, 4096, 14336) == 8
+    assert lib.swl_gemm_packed_mid_choose_splits(128, 4096, 14336) == 8
+    assert lib.swl_gemm_packed_mid_choose_splits(64, 28672, 4096) == 1
+    assert lib.swl_gemm_packed_mid_choose_splits(129, 4096, 4096) == 0    # M > 128
+    # argument validation of the packed entry points (no launch)
+    assert lib.swl_gemm_pack_weight(None, None, 4096, 4096, _hip.SWL_BF16, None) == -1
+    assert lib.swl_gemm_skinny_packed(None, None, None, None, 0, 0, 4096, 4096, 4096, 4096, 0, _hip.SWL_BF16, None) == 0
+    assert lib.swl_gemm_packed_mid(None, None, None, None, 0, 0, 4096, 4096, 4096, 4096, 0, _hip.SWL_BF16, None) == 0

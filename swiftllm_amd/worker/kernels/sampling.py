@@ -4,6 +4,7 @@ import torch
 from swiftllm_amd import _hip
 
 _scratch = {}   # device -> persistent candidate buffer (fixed address: hipGraph replays use it)
+_retired = []   # outgrown buffers stay allocated: a captured hipGraph may still replay against them
 
 
 def argmax_rows(logits: torch.Tensor) -> torch.Tensor:
@@ -15,6 +16,8 @@ def argmax_rows(logits: torch.Tensor) -> torch.Tensor:
     need = _hip.load().swl_argmax_scratch_bytes(rows)
     buf = _scratch.get(logits.device)
     if buf is None or buf.numel() < need:
+        if buf is not None:
+            _retired.append(buf)
         buf = torch.empty(max(need, 512 * 64 * 8), dtype=torch.uint8, device=logits.device)
         _scratch[logits.device] = buf
     out = torch.empty((rows,), dtype=torch.int64, device=logits.device)

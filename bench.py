@@ -359,7 +359,7 @@ def main():
                    "parallelism": f"request-sharded dp{world} (independent replicas, no collective)",
                    "hip_graph": not args.no_hip_graph, "fuse_qkv": args.fuse_qkv,
                    "skinny_gemm": args.skinny_gemm, "packed_decode_weights": getattr(args, "packed_weights", True),
-                   "kv_blocks": num_blocks},
+                   "kv_blocks": num_blocks, "decode_graphs_captured": len(getattr(model, "_decode_graphs", {}))},
         "prefill_tok_s": round(prefill_units / prefill_max_s, 1),
         "prefill_ms": round(prefill_max_s * 1e3, 2),
         "step_roofline": {"bound": "hbm", "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -261,6 +261,10 @@ int swl_gemm_packed_mid(void *out, const void *x, const void *w_packed, void *wo
                         int32_t M, int32_t N, int32_t K, int64_t x_row_stride, int64_t out_row_stride,
                         int32_t k_splits, int32_t dtype, swl_stream_t stream);
 int swl_gemm_packed_mid_choose_splits(int32_t M, int32_t N, int32_t K); /* its choice for k_splits = 0 */
+/* ... with the SiLU-gate of the FFN in its epilogue: out[M, I] = up * silu(gate), W = [up ; gate] packed */
+int swl_gemm_packed_mid_silu_gate(void *out, const void *x, const void *w_up_gate_packed, int32_t M, int32_t I,
+                                  int32_t K, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype,
+                                  swl_stream_t stream);
 /* ... stopping at the fp32 partial slabs [k_splits][M][N] (k_splits >= 1) for the split-K consumers */
 int swl_gemm_packed_mid_partial(float *slabs, size_t slabs_bytes, const void *x, const void *w_packed, int32_t M,
                                 int32_t N, int32_t K, int64_t x_row_stride, int32_t k_splits, int32_t dtype,

@@ -59,6 +59,7 @@ SIGNATURES = {
     "swl_gemm_pack_weight": [_P, _P, _I32, _I32, _I32, _P],
     "swl_gemm_skinny_packed": [_P, _P, _P, _P, ctypes.c_size_t, _I32, _I32, _I32, _I64, _I64, _I32, _I32, _P],
     "swl_gemm_packed_mid_partial": [_P, ctypes.c_size_t, _P, _P, _I32, _I32, _I32, _I64, _I32, _I32, _P],
+    "swl_gemm_packed_mid_silu_gate": [_P, _P, _P, _I32, _I32, _I32, _I64, _I64, _I32, _P],
     "swl_gemm_packed_mid": [_P, _P, _P, _P, ctypes.c_size_t, _I32, _I32, _I32, _I64, _I64, _I32, _I32, _P],
     "swl_gemm_skinny_packed_partial": [_P, ctypes.c_size_t, _P, _P, _I32, _I32, _I32, _I64, _I32, _I32, _P],
     "swl_gemm_skinny_packed_silu_gate": [_P, _P, _P, _I32, _I32, _I32, _I64, _I64, _I32, _P],

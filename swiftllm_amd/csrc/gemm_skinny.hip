@@ -1001,10 +1001,14 @@ extern "C" int swl_gemm_skinny_packed_silu_gate(void *out, const void *x, const 
 // streams these shapes at 1.3-4.7 TB/s (profiles/r01e_hipblaslt_m48_256.jsonl).
 namespace swl {
 
-template <typename T, int MT, bool PARTIAL>
+// MODE as in the M <= 32 kernels: kGemmDirect, kGemmPartial (fp32 slabs) or kGemmSiluGate (W = [up ; gate], N = I:
+// waves 0,1 own `up` tiles, waves 2,3 the `gate` tiles of the same columns; the activated gate tiles change hands
+// through the x buffers after the last K-tile).
+template <typename T, int MT, int MODE>
 __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_packed_mt_kernel(
     void *__restrict__ out_, const T *__restrict__ x, const T *__restrict__ wpk, int M, int N, int K, int kc,
     int64_t x_stride, int64_t out_stride) {
+    constexpr bool PARTIAL = MODE == kGemmPartial;
     constexpr int D = kRing;
     constexpr int XL = MT * 8 / kGemmWaves; // x row-groups (4 rows each) a wave stages per tile
     constexpr int kXTile = MT * 32 * kKT;
@@ -1012,9 +1016,11 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_packed_mt_kernel(
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int col0 = (blockIdx.x * kGemmWaves + wave) * 32;
+    const bool is_gate = MODE == kGemmSiluGate && wave >= 2;
+    const int col0 = MODE == kGemmSiluGate ? (blockIdx.x * 2 + (wave & 1)) * 32
+                                           : (blockIdx.x * kGemmWaves + wave) * 32;
     const bool tile_ok = col0 < N;
-    const int nt = tile_ok ? col0 / 32 : 0;
+    const int nt = tile_ok ? (col0 + (is_gate ? N : 0)) / 32 : 0;
     const int ksplit = blockIdx.y;
     const int k_begin = ksplit * kc;
     const int nkt = kc / kKT;
@@ -1095,6 +1101,40 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_packed_mt_kernel(
 #undef SWL_MT_ISSUE_X
 #undef SWL_MT_STAGE_X
 #undef SWL_MT_PROCESS
+    if constexpr (MODE == kGemmSiluGate) {
+        // same rounding points as linear -> silu_and_mul_inplace: projection rounded to T, silu in fp32 rounded to
+        // T, product in T. Exchange tile of (gate wave w, token block mt): 32 x 40 elements in the x buffers.
+        __syncthreads(); // every wave is done reading the x tiles
+        T *xch = xs + ((wave & 1) * MT) * 1280;
+        if (is_gate) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float g = to_f(to_t<T>(acc[mt][r]));
+                    xch[mt * 1280 + l32 * 40 + (r & 3) + 8 * (r >> 2) + 4 * hf] = to_t<T>(g / (1.0f + expf(-g)));
+                }
+        }
+        __syncthreads();
+        if (!is_gate && tile_ok) {
+            typedef T vec4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = 32 * mt + l32;
+                if (m >= M) continue;
+                T *o = static_cast<T *>(out_) + static_cast<int64_t>(m) * out_stride + col0 + 4 * hf;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const vec4 a = *reinterpret_cast<const vec4 *>(xch + mt * 1280 + l32 * 40 + 8 * r4 + 4 * hf);
+                    vec4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = mul_t<T>(to_t<T>(acc[mt][4 * r4 + e]), a[e]);
+                    *reinterpret_cast<vec4 *>(o + 8 * r4) = v;
+                }
+            }
+        }
+        return;
+    }
     if (!tile_ok) return;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -1142,17 +1182,17 @@ static int run_gemm_packed_mt(T *out, const T *x, const T *wp, float *ws, size_t
     const int kc = K / ks;
     if (ks == 1 && reduce) {
         if (M <= 64)
-            hipLaunchKernelGGL((gemm_packed_mt_kernel<T, 2, false>), grid, block, 0, stream, out, x, wp, M, N, K, kc, xs, os);
+            hipLaunchKernelGGL((gemm_packed_mt_kernel<T, 2, kGemmDirect>), grid, block, 0, stream, out, x, wp, M, N, K, kc, xs, os);
         else
-            hipLaunchKernelGGL((gemm_packed_mt_kernel<T, 4, false>), grid, block, 0, stream, out, x, wp, M, N, K, kc, xs, os);
+            hipLaunchKernelGGL((gemm_packed_mt_kernel<T, 4, kGemmDirect>), grid, block, 0, stream, out, x, wp, M, N, K, kc, xs, os);
         return check_launch();
     }
     if (!ws || ws_bytes < static_cast<size_t>(ks) * M * N * sizeof(float)) return SWL_ERR_BAD_ARG;
     const int64_t n64 = N;
     if (M <= 64)
-        hipLaunchKernelGGL((gemm_packed_mt_kernel<T, 2, true>), grid, block, 0, stream, ws, x, wp, M, N, K, kc, xs, n64);
+        hipLaunchKernelGGL((gemm_packed_mt_kernel<T, 2, kGemmPartial>), grid, block, 0, stream, ws, x, wp, M, N, K, kc, xs, n64);
     else
-        hipLaunchKernelGGL((gemm_packed_mt_kernel<T, 4, true>), grid, block, 0, stream, ws, x, wp, M, N, K, kc, xs, n64);
+        hipLaunchKernelGGL((gemm_packed_mt_kernel<T, 4, kGemmPartial>), grid, block, 0, stream, ws, x, wp, M, N, K, kc, xs, n64);
     if (!reduce) return check_launch();
     const int64_t items = static_cast<int64_t>(M) * (N / 4);
     hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(static_cast<unsigned>((items + 255) / 256)), dim3(256), 0,
@@ -1209,4 +1249,31 @@ extern "C" int swl_gemm_packed_mid_partial(float *slabs, size_t slabs_bytes, con
                                           static_cast<const T *>(w_packed), slabs, slabs_bytes, M, N, K, x_row_stride, N,
                                           k_splits, static_cast<hipStream_t>(stream), false);
     });
+}
+
+/* out[M, I] = up * silu(gate) of x . [up ; gate]^T for 32 < M <= 128 tokens on a packed weight (the medium-batch
+ * twin of swl_gemm_skinny_packed_silu_gate; same rounding points as linear + silu_and_mul). I % 32 == 0. */
+extern "C" int swl_gemm_packed_mid_silu_gate(void *out, const void *x, const void *w_up_gate_packed, int32_t M,
+                                             int32_t I, int32_t K, int64_t x_row_stride, int64_t out_row_stride,
+                                             int32_t dtype, swl_stream_t stream) {
+    if (M < 0 || I <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
+    if (M == 0) return SWL_OK;
+    if (!out || !x || !w_up_gate_packed) return SWL_ERR_BAD_ARG;
+    if (M > 128 || (I & 31) || (K & (swl::kKT - 1))) return SWL_ERR_UNSUPPORTED;
+    if (x_row_stride < K || out_row_stride < I || (x_row_stride & 7) || (out_row_stride & 3)) return SWL_ERR_BAD_ARG;
+    if (!swl::aligned16(x) || !swl::aligned16(w_up_gate_packed) || (reinterpret_cast<uintptr_t>(out) & 7u))
+        return SWL_ERR_BAD_ARG;
+    const dim3 grid((I / 32 + 1) / 2, 1), block(swl::kGemmWaves * 64);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    SWL_DISPATCH_DTYPE(dtype, T, {
+        if (M <= 64)
+            hipLaunchKernelGGL((swl::gemm_packed_mt_kernel<T, 2, swl::kGemmSiluGate>), grid, block, 0, s, out,
+                               static_cast<const T *>(x), static_cast<const T *>(w_up_gate_packed), M, I, K, K,
+                               x_row_stride, out_row_stride);
+        else
+            hipLaunchKernelGGL((swl::gemm_packed_mt_kernel<T, 4, swl::kGemmSiluGate>), grid, block, 0, s, out,
+                               static_cast<const T *>(x), static_cast<const T *>(w_up_gate_packed), M, I, K, K,
+                               x_row_stride, out_row_stride);
+    });
+    return swl::check_launch();
 }

@@ -163,6 +163,13 @@ def linear_silu_gate(a: torch.Tensor, w_up_gate: torch.Tensor):
     """The FFN's `silu_and_mul_inplace(linear(a, up_gate_proj))[:, :I]` in one launch for decode-sized
     batches: returns [T, I], or None when the shapes do not qualify (the caller then takes the two-op
     path)."""
+    if _mid_ok(a, w_up_gate) and a.shape[0] <= 64 and w_up_gate.shape[0] % 64 == 0:   # medium batch, packed weight
+        m, k = a.shape
+        inter = w_up_gate.shape[0] // 2
+        out = torch.empty((m, inter), dtype=a.dtype, device=a.device)
+        _hip.call("swl_gemm_packed_mid_silu_gate", _hip.ptr(out), _hip.ptr(a), _hip.ptr(_packed_of(w_up_gate)), m,
+                  inter, k, _row_stride(a), inter, _hip.dtype_code(a.dtype), _hip.stream())
+        return out
     if not _skinny_ok(a, w_up_gate) or w_up_gate.shape[0] % 64 != 0:
         return None
     m, k = a.shape

@@ -813,3 +813,25 @@ def test_gemm_packed_mid_vs_fp32_reference(dtype, M, N, K):
         _hip.call("swl_gemm_packed_mid", out.data_ptr(), x.data_ptr(), wp.data_ptr(), ws.data_ptr(), ws.numel() * 4,
                   M, N, K, K, N, ks, code, _hip.stream())
         assert ((out.float() - ref).abs() <= eps * ref.abs() + 1e-3 * eps * (K ** 0.5)).all(), ks
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,I,Kd", [(48, 14336, 4096), (64, 11008, 4096), (33, 256, 128), (100, 96, 384),
+                                    (128, 160, 1280), (7, 96, 1152)])
+def test_gemm_packed_mid_silu_gate_equals_two_ops(dtype, M, I, Kd):
+    """Medium-batch SiLU-gate GEMM == medium-batch GEMM (one k-split) followed by silu_and_mul, bit for bit."""
+    from swiftllm_amd import _hip
+    g = gen(M + I)
+    x = torch.randn(M, Kd, generator=g).to(dtype).cuda()
+    w = (torch.randn(2 * I, Kd, generator=g) * 0.03).to(dtype).cuda()
+    code = _hip.dtype_code(dtype)
+    wp = torch.empty_like(w)
+    _hip.call("swl_gemm_pack_weight", wp.data_ptr(), w.data_ptr(), 2 * I, Kd, code, _hip.stream())
+    fused = torch.empty(M, I, dtype=dtype, device="cuda")
+    _hip.call("swl_gemm_packed_mid_silu_gate", fused.data_ptr(), x.data_ptr(), wp.data_ptr(), M, I, Kd, Kd, I, code,
+              _hip.stream())
+    two = torch.empty(M, 2 * I, dtype=dtype, device="cuda")
+    _hip.call("swl_gemm_packed_mid", two.data_ptr(), x.data_ptr(), wp.data_ptr(), 0, 0, M, 2 * I, Kd, Kd, 2 * I, 1, code,
+              _hip.stream())
+    K().silu_and_mul_inplace(two)
+    assert torch.equal(fused, two[:, :I])

@@ -1,4 +1,14 @@
-// gemm_skinny.hip — weight-streaming GEMM for decode batches (M <= 32 tokens) on gfx950.
+// gemm_skinny.hip — weight-streaming GEMMs for decode batches on gfx950.
+//
+// Map of this file (all variants share the tile geometry and the MFMA order, hence their bits):
+//   gemm_skinny_kernel       row-major W, wave-private W and x tiles, no barriers   (short K-chunks, M <= 32)
+//   gemm_skinny_ring_kernel  x tile shared by the workgroup, register ring of W tiles (M <= 32)
+//        PACKED = false      ... row-major W through a wave-private LDS transpose
+//        PACKED = true       ... W pre-packed in MFMA-fragment order (swl_gemm_pack_weight): global -> VGPR -> MFMA;
+//                                the default decode path (EngineConfig.pack_decode_weights)
+//        XNORM / EPI hooks   ... experimental fused decode layer (off by default)
+//   gemm_packed_mt_kernel    packed W, 2 or 4 blocks of 32 tokens per weight fragment (32 < M <= 128)
+//   splitk_reduce_kernel, pack_weight_kernel
 //
 // out[M, N] = x[M, K] . W[N, K]^T  — the shape of every projection of a decode step
 // (reference: swiftllm/worker/kernels/linear.py:3-12 called from transformer_layer.py:54-56,117,

@@ -46,9 +46,11 @@ def build_app(engine: Engine) -> fastapi.FastAPI:
                     state["outstanding_tokens"] -= cost
             return StreamingResponse(lines(), media_type="text/plain")
         try:
-            _, token_ids = await engine.add_request_and_wait(raw)
+            request, token_ids = await engine.add_request_and_wait(raw)
         finally:
             state["outstanding_tokens"] -= cost
+        if request.error is not None:
+            return JSONResponse({"error": request.error}, status_code=400)
         if want_text:
             return JSONResponse({"output": await engine.tokenization_engine.decode(token_ids)})
         return JSONResponse({"output_token_ids": token_ids})

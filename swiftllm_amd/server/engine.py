@@ -72,6 +72,8 @@ class Engine:
         request = self._enqueue(raw_request)
         while True:
             step_output = await request.output_q.get()
+            if step_output is None:     # rejected (request.error says why)
+                break
             yield step_output
             request.output_q.task_done()
             if step_output.request.is_finished() and request.output_q.empty():
@@ -96,7 +98,15 @@ class Engine:
                 for (req, _), token_ids in zip(texts, ids):
                     req.prompt_token_ids = list(token_ids)
                     req.prompt_len = len(token_ids)
-            self.scheduler.on_requests_arrival([req for req, _ in pending])
+            servable = []
+            for req, _ in pending:
+                req.error = self.scheduler.why_unservable(req)
+                if req.error is None:
+                    servable.append(req)
+                else:           # answer at once: waiters wake up with no tokens, streams end
+                    req.finished_event.set()
+                    req.output_q.put_nowait(None)
+            self.scheduler.on_requests_arrival(servable)
             await asyncio.sleep(0.001)
 
     async def step(self) -> bool:

@@ -14,7 +14,7 @@ Two deliberate differences:
     requests — an iterator that is always truthy, so its idle engine never sleeps (engine.py:122).
 """
 from collections import deque
-from typing import Deque, List, Tuple
+from typing import Optional, Deque, List, Tuple
 
 from swiftllm_amd.utils import cdiv
 from .structs import Request
@@ -58,6 +58,25 @@ class Scheduler:
         return sum(self._blocks(r) for r in self.running_q)
 
     # ---- events --------------------------------------------------------------------------------------
+    def why_unservable(self, req: Request) -> Optional[str]:
+        """None, or the reason this request could never run to completion under the engine's limits. Such a
+        request must not enter the queues: strict FCFS would park everything behind it (a prompt over the token
+        budget is never admitted) or it would swap in and out forever (a sequence larger than the pool). The
+        reference has no such check and hangs (scheduler.py:60-90)."""
+        ecfg = self.engine_config
+        if req.prompt_len <= 0:
+            return "empty prompt"
+        if req.output_len <= 0:
+            return "output_len must be positive"
+        if req.prompt_len > ecfg.max_tokens_in_batch:
+            return f"prompt of {req.prompt_len} tokens exceeds max_tokens_in_batch ({ecfg.max_tokens_in_batch})"
+        blocks = cdiv(req.prompt_len + req.output_len, ecfg.block_size)
+        if blocks > ecfg.max_blocks_per_seq:
+            return f"sequence needs {blocks} KV blocks, max_blocks_per_seq is {ecfg.max_blocks_per_seq}"
+        if blocks > self.num_gpu_blocks:
+            return f"sequence needs {blocks} KV blocks, the pool has {self.num_gpu_blocks}"
+        return None
+
     def on_requests_arrival(self, requests: List[Request]):
         self.waiting_q.extend(requests)
 

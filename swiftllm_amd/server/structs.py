@@ -33,6 +33,7 @@ class Request:
         self.finished_event = asyncio.Event()                           # non-streaming consumers wait here
         self.request_id = -1            # row of the block table, assigned when the request is admitted
         self.output_token_ids: List[int] = []
+        self.error: Optional[str] = None    # set instead of scheduling when the request can never be served
 
     def is_finished(self) -> bool:
         return len(self.output_token_ids) >= self.output_len

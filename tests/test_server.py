@@ -190,6 +190,8 @@ def test_api_server_generate_endpoint():
         r = client.post("/generate", json={"prompt_token_ids": [8], "output_len": 4, "stream": True})
         assert [int(x) for x in r.text.split()] == _expected([8], 4)
         assert client.get("/load").json() == {"outstanding_tokens": 0}
+        r = client.post("/generate", json={"prompt_token_ids": list(range(200)), "output_len": 3})
+        assert r.status_code == 400 and "max_tokens_in_batch" in r.json()["error"]
 
 
 def test_replica_router_balances_by_outstanding_tokens():
@@ -201,3 +203,29 @@ def test_replica_router_balances_by_outstanding_tokens():
     assert r.acquire(1) == 0
     assert request_cost({"prompt_token_ids": [1, 2, 3], "output_len": 7}) == 10
     assert request_cost({"prompt": "a b c d", "output_len": 1}) == 5
+
+
+def test_unservable_requests_are_rejected_not_queued():
+    s = Scheduler(None, _cfg(max_tokens_in_batch=64, max_blocks_per_seq=8), num_gpu_blocks=6)
+    assert s.why_unservable(_req(10, 4)) is None
+    assert "max_tokens_in_batch" in s.why_unservable(_req(65, 1))
+    assert "max_blocks_per_seq" in s.why_unservable(_req(60, 100))        # 160 tokens = 10 blocks > 8
+    assert "pool" in s.why_unservable(_req(60, 45))                        # 105 tokens = 7 blocks > 6 in the pool
+    assert "empty" in s.why_unservable(_req(0, 4))
+
+    async def run():
+        model = FakeModel()
+        eng = Engine(_cfg(max_tokens_in_batch=16), model=model)
+        await eng.initialize()
+        loops = asyncio.ensure_future(eng.start_all_event_loops())
+        bad = asyncio.ensure_future(eng.add_request_and_wait(RawRequest("", 3, list(range(17)))))
+        good = asyncio.ensure_future(eng.add_request_and_wait(RawRequest("", 3, [1, 2])))
+
+        async def stream_bad():
+            return [s async for s in eng.add_request_and_stream(RawRequest("", 3, list(range(40))))]
+        (breq, btoks), (greq, gtoks), streamed = await asyncio.wait_for(asyncio.gather(bad, good, stream_bad()), 20)
+        loops.cancel()
+        return breq, btoks, greq, gtoks, streamed
+    breq, btoks, greq, gtoks, streamed = asyncio.run(run())
+    assert breq.error and btoks == [] and streamed == []
+    assert greq.error is None and gtoks == _expected([1, 2], 3)             # the queue behind it keeps moving

@@ -8,6 +8,11 @@ hand-written weight-streaming MFMA kernel `swl_gemm_skinny` (csrc/gemm_skinny.hi
 projection is pure HBM streaming of the weight matrix, 77 % of all bytes a decode step moves
 (SURVEY.md §8f rank 1). Larger M (prefill) stays on the BLAS, which is compute-bound territory.
 
+Weights that carry a packed twin (`pack_weight`: a copy in MFMA-fragment order made at load time,
+EngineConfig.pack_decode_weights) are streamed from that copy — same bits, 6-9 % faster (long sequential DRAM
+bursts, no LDS transpose) — and additionally serve decode batches of 33..128 tokens (`swl_gemm_packed_mid`: 2 or 4
+blocks of 32 tokens share every weight fragment; used up to 64 tokens, and above that where K >= 2N).
+
 `linear_splitk` is the same product stopped one step earlier: when the kernel splits K across
 workgroups it returns the fp32 partial slabs (`SplitKPartials`) instead of launching the reduce, and a
 fused consumer (`fused_add_rmsnorm_from_splitk`, `rotary_embedding_and_store_kvcache_decode_from_splitk`)

@@ -229,3 +229,75 @@ def test_unservable_requests_are_rejected_not_queued():
     breq, btoks, greq, gtoks, streamed = asyncio.run(run())
     assert breq.error and btoks == [] and streamed == []
     assert greq.error is None and gtoks == _expected([1, 2], 3)             # the queue behind it keeps moving
+
+
+def test_router_relays_to_live_replicas_and_balances():
+    """Two fake replicas (real HTTP servers on localhost) behind the router app: JSON and streamed answers are
+    relayed unchanged, consecutive requests spread over the replicas, the books return to zero."""
+    import socket
+    import threading
+    import time
+    import fastapi
+    import uvicorn
+    from fastapi.responses import JSONResponse, StreamingResponse
+    from fastapi.testclient import TestClient
+    from swiftllm_amd.server.router import build_app
+
+    def free_port():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            return s.getsockname()[1]
+
+    served = {}
+    servers = []
+
+    def make_replica(tag):
+        app = fastapi.FastAPI()
+
+        @app.post("/generate")
+        async def generate(req: fastapi.Request):
+            body = await req.json()
+            served[tag] = served.get(tag, 0) + 1
+            n = int(body["output_len"])
+            if body.get("stream"):
+                async def lines():
+                    for i in range(n):
+                        await asyncio.sleep(0.01)
+                        yield f"{tag}{i}\n"
+                return StreamingResponse(lines(), media_type="text/plain")
+            await asyncio.sleep(0.2)        # long enough for the next request to see this one outstanding
+            return JSONResponse({"output_token_ids": [tag] * n})
+        return app
+
+    urls = []
+    for tag in (7, 9):
+        port = free_port()
+        server = uvicorn.Server(uvicorn.Config(make_replica(tag), host="127.0.0.1", port=port, log_level="error"))
+        threading.Thread(target=server.run, daemon=True).start()
+        servers.append(server)
+        urls.append(f"http://127.0.0.1:{port}")
+    deadline = time.time() + 10
+    while not all(s.started for s in servers):
+        assert time.time() < deadline, "fake replicas did not start"
+        time.sleep(0.05)
+    try:
+        router = ReplicaRouter(urls)
+        with TestClient(build_app(router)) as client:
+            results = []
+
+            def post(n):
+                results.append(client.post("/generate", json={"prompt_token_ids": [1, 2, 3], "output_len": n}).json())
+            threads = [threading.Thread(target=post, args=(n,)) for n in (3, 4)]
+            for t in threads:
+                t.start()
+                time.sleep(0.05)
+            for t in threads:
+                t.join()
+            assert sorted(len(r["output_token_ids"]) for r in results) == [3, 4]
+            assert served == {7: 1, 9: 1}                       # the second request avoided the busy replica
+            r = client.post("/generate", json={"prompt_token_ids": [5], "output_len": 3, "stream": True})
+            assert r.text.split() in (["70", "71", "72"], ["90", "91", "92"])
+            assert client.get("/load").json() == {"outstanding_tokens": [0, 0]}
+    finally:
+        for s in servers:
+            s.should_exit = True

@@ -297,3 +297,30 @@ def test_swiftllm_alias_resolves_to_this_implementation():
     assert paged_attention.__module__ == "swiftllm_amd.worker.kernels.paged_attn"
     with pytest.raises(ImportError):
         import swiftllm.no_such_module  # noqa: F401
+
+
+def test_streaming_loader_reads_sharded_checkpoints(tmp_path):
+    """model.safetensors.index.json + several shard files (what HuggingFace writes for 8B+ models)."""
+    import json
+    from safetensors.torch import save_file
+    cfg = synth.make_config()
+    sd = synth.make_state_dict(cfg, seed=6)
+    synth.write_model_dir(str(tmp_path), cfg)            # config.json only
+    keys = sorted(sd)
+    shards = {"model-00001-of-00003.safetensors": keys[0::3], "model-00002-of-00003.safetensors": keys[1::3],
+              "model-00003-of-00003.safetensors": keys[2::3]}
+    for name, ks in shards.items():
+        save_file({k: sd[k].contiguous() for k in ks}, str(tmp_path / name))
+    with open(tmp_path / "model.safetensors.index.json", "w", encoding="utf-8") as f:
+        json.dump({"weight_map": {k: name for name, ks in shards.items() for k in ks}}, f)
+    mc = LlamaModelConfig.load_from_model_path(str(tmp_path))
+    for streaming in (True, False):
+        w = load_weights(mc, torch.float16, str(tmp_path), device="cpu", fuse_qkv=True, streaming=streaming)
+        assert torch.equal(w.wte, sd["model.embed_tokens.weight"])
+        l0 = w.layers[0]
+        assert torch.equal(l0.qkv_proj, torch.cat([sd[f"model.layers.0.self_attn.{n}_proj.weight"] for n in "qkv"]))
+        assert torch.equal(l0.up_gate_proj, torch.cat((sd["model.layers.0.mlp.up_proj.weight"],
+                                                       sd["model.layers.0.mlp.gate_proj.weight"])))
+    (tmp_path / "model.safetensors.index.json").unlink()
+    with pytest.raises(AssertionError, match="index.json not found"):
+        load_weights(mc, torch.float16, str(tmp_path), device="cpu")

@@ -265,7 +265,7 @@ def test_router_relays_to_live_replicas_and_balances():
                         await asyncio.sleep(0.01)
                         yield f"{tag}{i}\n"
                 return StreamingResponse(lines(), media_type="text/plain")
-            await asyncio.sleep(0.2)        # long enough for the next request to see this one outstanding
+            await asyncio.sleep(0.6)        # long enough for the next request to see this one outstanding
             return JSONResponse({"output_token_ids": [tag] * n})
         return app
 
@@ -290,7 +290,7 @@ def test_router_relays_to_live_replicas_and_balances():
             threads = [threading.Thread(target=post, args=(n,)) for n in (3, 4)]
             for t in threads:
                 t.start()
-                time.sleep(0.05)
+                time.sleep(0.15)
             for t in threads:
                 t.join()
             assert sorted(len(r["output_token_ids"]) for r in results) == [3, 4]

@@ -26,6 +26,11 @@ class _AliasLoader(importlib.abc.Loader):
     def exec_module(self, module):
         pass
 
+    def get_code(self, fullname):
+        # `python -m swiftllm.server.api_server`: runpy runs the code of the real module as __main__
+        real = self._module.__name__
+        return importlib.util.find_spec(real).loader.get_code(real)
+
 
 class _AliasFinder(importlib.abc.MetaPathFinder):
     def find_spec(self, fullname, path=None, target=None):
@@ -35,7 +40,8 @@ class _AliasFinder(importlib.abc.MetaPathFinder):
             real = importlib.import_module(_REAL + fullname[len(_PREFIX):])
         except ImportError:
             return None
-        return importlib.util.spec_from_loader(fullname, _AliasLoader(real), is_package=hasattr(real, "__path__"))
+        return importlib.util.spec_from_loader(fullname, _AliasLoader(real), origin=getattr(real, "__file__", None),
+                                               is_package=hasattr(real, "__path__"))
 
 
 sys.meta_path.insert(0, _AliasFinder())

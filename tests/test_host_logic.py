@@ -6,6 +6,8 @@ import random
 import types
 
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -284,6 +286,16 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f), encoding="utf-8").read()
                 assert "import oracle" not in text and "from oracle" not in text, os.path.join(dirpath, f)
+
+
+def test_swiftllm_alias_runs_modules_with_dash_m():
+    """`python -m swiftllm.server.api_server` (the reference's launch line) goes through the alias."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "swiftllm.server.api_server", "--help"], cwd=root, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0 and "--model-path" in r.stdout, r.stderr[-500:]
 
 
 def test_swiftllm_alias_resolves_to_this_implementation():

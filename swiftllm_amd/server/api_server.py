@@ -23,14 +23,40 @@ from .engine import Engine
 from .structs import RawRequest
 
 
+def _validate_body(body) -> "str | None":
+    """Shape checks the engine must never have to survive (it dies on any exception, taking every in-flight
+    request with it): types only — ranges (vocabulary, rotary positions, pool size) are the scheduler's
+    `why_unservable`, answered with the same 400."""
+    if not isinstance(body, dict):
+        return "body must be a JSON object"
+    n = body.get("output_len")
+    if not isinstance(n, int) or isinstance(n, bool):
+        return "output_len must be an integer"
+    ids = body.get("prompt_token_ids")
+    if ids is not None:
+        if not isinstance(ids, list) or not all(isinstance(t, int) and not isinstance(t, bool) for t in ids):
+            return "prompt_token_ids must be a list of integers"
+        if any(t < 0 or t >= 2 ** 31 for t in ids):
+            return "prompt_token_ids out of range"
+    elif not isinstance(body.get("prompt", ""), str):
+        return "prompt must be a string"
+    return None
+
+
 def build_app(engine: Engine) -> fastapi.FastAPI:
     app = fastapi.FastAPI()
     state = {"outstanding_tokens": 0}
 
     @app.post("/generate")
     async def generate(req: fastapi.Request):
-        body = await req.json()
-        raw = RawRequest(body.get("prompt", ""), int(body["output_len"]), body.get("prompt_token_ids"))
+        try:
+            body = await req.json()
+        except Exception:     # noqa: BLE001 — malformed JSON is the client's problem, not the engine's
+            return JSONResponse({"error": "body must be a JSON object"}, status_code=400)
+        problem = _validate_body(body)
+        if problem is not None:
+            return JSONResponse({"error": problem}, status_code=400)
+        raw = RawRequest(body.get("prompt", ""), body["output_len"], body.get("prompt_token_ids"))
         want_text = bool(body.get("decode", False))
         cost = raw.output_len + len(raw.prompt_token_ids or raw.prompt.split())
         state["outstanding_tokens"] += cost

@@ -57,6 +57,9 @@ class Engine:
         elif num_gpu_blocks is None:
             num_gpu_blocks = self.model.num_blocks
         self.scheduler = Scheduler(self.model_config, self.engine_config, num_gpu_blocks, self.piggyback)
+        rope = getattr(self.model, "_cos_cached", None)
+        if rope is not None:     # a request that would outgrow the rotary table is refused up front (HTTP 400),
+            self.scheduler.max_seq_len = int(rope.shape[0])     # not left to raise inside forward mid-flight
         self.tokenization_engine = TokenizationEngine(self.engine_config)
         self.initialized = True
         print("[Engine] Model initialized")

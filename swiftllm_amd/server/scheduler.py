@@ -49,6 +49,10 @@ class Scheduler:
         self.running_q: List[Request] = []
         self.swapped_q: Deque[Request] = deque()
         self.request_id_manager = RequestIdManager(engine_config.max_seqs_in_block_table)
+        # limits of the data plane the Engine fills in once the model exists (None = unknown, not checked):
+        # rows of the rotary table (LlamaModel.forward raises past it) and the vocabulary size
+        self.max_seq_len: Optional[int] = None
+        self.vocab_size: Optional[int] = getattr(model_config, "vocab_size", None)
 
     # ---- budgets -------------------------------------------------------------------------------------
     def _blocks(self, req: Request, extra_tokens: int = 0) -> int:
@@ -68,6 +72,14 @@ class Scheduler:
             return "empty prompt"
         if req.output_len <= 0:
             return "output_len must be positive"
+        ids = req.prompt_token_ids
+        if self.vocab_size is not None and ids is not None:
+            # ids index the embedding table on the device: out-of-range values must never reach a kernel
+            if not all(isinstance(t, int) and not isinstance(t, bool) and 0 <= t < self.vocab_size for t in ids):
+                return f"prompt_token_ids must be integers in [0, {self.vocab_size})"
+        if self.max_seq_len is not None and req.prompt_len + req.output_len > self.max_seq_len:
+            return (f"prompt ({req.prompt_len}) + output_len ({req.output_len}) exceeds the model's "
+                    f"{self.max_seq_len} rotary positions")
         if req.prompt_len > ecfg.max_tokens_in_batch:
             return f"prompt of {req.prompt_len} tokens exceeds max_tokens_in_batch ({ecfg.max_tokens_in_batch})"
         blocks = cdiv(req.prompt_len + req.output_len, ecfg.block_size)

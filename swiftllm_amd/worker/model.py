@@ -84,7 +84,8 @@ class LlamaModel:
         self._meta_dev = None       # its device twin (fixed address: hipGraph replays read it)
         self._meta_done = None
         self._num_slots = 256        # CUs: one 8-wave paged-attention workgroup each
-        self._decode_graphs = {}
+        self._decode_graphs = {}     # (batch, split width, split count) -> _DecodeGraph, in LRU order
+        self._graph_pool = None
         self._scratch = None
 
     # ------------------------------------------------------------------------------------------------
@@ -260,23 +261,32 @@ class LlamaModel:
         return self.post_layer.forward(x, infer_state)
 
     # ---- hipGraph replay of pure-decode steps ------------------------------------------------------------
+    _MAX_DECODE_GRAPHS = 24     # LRU bound of the replay cache (each graph pins its activations + [B, vocab] logits)
+
     def _graph_bucket(self, plan: BatchPlan):
-        """Captured launch geometry must cover every replay: the split count is taken for the longest
-        sequence rounded up to its next 64-token boundary (the granule select_seq_block_size works
-        in) and then to a power of two, so a graph stays valid while sequences grow (surplus
-        workgroups exit on their first instruction). A single split stays a single split."""
+        """Captured launch geometry must cover every replay, and the number of distinct geometries a long-running
+        server meets must stay small (every new one costs a warm-up run + a capture, and memory): the split width
+        is rounded up to a power of two — `select_seq_block_size` drifts in 64-token steps as sequences grow — and
+        the split count is taken for the longest sequence rounded up to its next 64-token boundary and then to a
+        power of two (surplus workgroups exit on their first instruction). A single split stays a single split
+        (its width only has to cover the longest sequence)."""
         sbs = plan.seq_block_size
+        if plan.num_seq_blocks > 1:
+            sbs = 1 << (sbs - 1).bit_length()
         horizon = -(-(plan.max_decoding_len + 1) // 64) * 64
         nsb_cap = -(-horizon // sbs)
         if nsb_cap > 1:
             nsb_cap = 1 << (nsb_cap - 1).bit_length()
+        else:
+            # one split: any width >= the longest sequence is the same launch; key on a power of two of it
+            sbs = max(256, 1 << (horizon - 1).bit_length())
         return sbs, nsb_cap
 
     def _forward_decode_graph(self, plan: BatchPlan, dev: dict) -> torch.Tensor:
         sbs, nsb_cap = self._graph_bucket(plan)
         key = (plan.batch_size, sbs, nsb_cap)
-        entry = self._decode_graphs.get(key)
-        plan.num_seq_blocks = nsb_cap
+        entry = self._decode_graphs.pop(key, None)
+        plan.seq_block_size, plan.num_seq_blocks = sbs, nsb_cap
         if entry is None:
             state = self._make_infer_state(plan, dev, False)
             # one eager run on a side stream first (library handles, workspaces, allocator pools):
@@ -286,12 +296,18 @@ class LlamaModel:
             with torch.cuda.stream(warm):
                 self._forward(dev["input_ids"], state)
             torch.cuda.current_stream().wait_stream(warm)
+            while len(self._decode_graphs) >= self._MAX_DECODE_GRAPHS:      # least recently used first
+                self._decode_graphs.pop(next(iter(self._decode_graphs)))
+            if self._graph_pool is None:
+                # ONE private memory pool for all captures: graphs never run concurrently (one stream), so they can
+                # share their activation memory instead of each pinning its own after the KV pool took the rest
+                self._graph_pool = torch.cuda.graph_pool_handle()
             entry = _DecodeGraph()
             entry.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(entry.graph):
+            with torch.cuda.graph(entry.graph, pool=self._graph_pool):
                 entry.out_tokens = self._forward(dev["input_ids"], state)
             entry.seq_block_size, entry.num_seq_blocks = sbs, nsb_cap
-            self._decode_graphs[key] = entry
+        self._decode_graphs[key] = entry        # (re)inserted last = most recently used
         entry.graph.replay()
         return entry.out_tokens
 

@@ -1,0 +1,184 @@
+"""End-to-end parity at Llama-3-8B WIDTH against the independent checker.
+
+Model: Llama-3-8B layer geometry (hidden 4096, 32 q / 8 kv heads of 128, FFN 14336, rope_theta 5e5), 2 layers,
+8k vocabulary (so the CPU side stays small). Workloads: BASELINE.json configs[1] (batch 1, 1024-token prompt,
+greedy decode) and a configs[2]-shaped ragged batch of 32 (lengths 1..1024). The HIP data plane — default path,
+hipGraph replay, row-major (unpacked) decode weights — is compared with oracle/ref_model.py, which is pinned to the
+reference's own run on the tiny golden (tests/test_oracle_golden.py), in BOTH decode-score modes:
+  * "fp32": exact scores (the reference's commented eager restatement, paged_attn.py:224-259);
+  * "ref" : the Triton kernel's fp16 products / fp16 sum / fp16 scale (paged_attn.py:17,72-73).
+The distance between those two oracles is the noise floor of the reference itself at this size: it is measured
+and reported beside ours, and the bars below are stated against it.
+
+Bars (fp16 — the reference's precision; written here, judged here):
+  * greedy token ids: identical to the fp32-score oracle at every step and sequence, except positions where the
+    oracle's own top-2 logit gap is below the measured logit distance (a near-tie no implementation can pin);
+  * pre-argmax logits: max |ours - oracle_fp32| <= 2 ulp of the storage dtype at the row's scale
+    (ulp(max|logit| of the row)); for reference, fp16 logits of magnitude 2..4 are spaced 1.95e-3 apart, so the
+    north star's absolute 1e-3 is sub-ulp here and is reported, not asserted, at this width. It IS asserted
+    where logits are small enough for it to be meaningful: tests/test_gpu_model.py (tiny golden).
+bf16 (headline dtype; the reference has no bf16 path): same checks against the oracle run in bf16, with the
+measured oracle_fp32-vs-oracle_bf16 distance printed — the tolerance is 2 bf16 ulp at the row's scale.
+A JSON report goes to gpurun_out/parity_fullwidth_<case>.json (copied to profiles/ when committed).
+"""
+import json
+import os
+
+import pytest
+import torch
+
+from oracle import synth
+from oracle.ref_model import RefLlamaModel
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = dict(num_hidden_layers=2, hidden_size=4096, num_attention_heads=32, num_key_value_heads=8,
+           intermediate_size=14336, vocab_size=8192, max_position_embeddings=2048, rope_theta=500000.0)
+CASES = {
+    # name: (prompt lengths, decode steps)
+    "configs1_batch1": ([1024], 12),
+    "configs2_batch32": ([1024, 1, 15, 16, 17, 100, 257, 640, 33, 1000, 511, 512, 513, 64, 128, 900,
+                          1024, 2, 31, 48, 300, 700, 800, 5, 1023, 256, 255, 77, 450, 999, 10, 129], 5),
+}
+VARIANTS = (("default", dict()), ("hipgraph", dict(use_hip_graph=True)),
+            ("row_major_weights", dict(pack_decode_weights=False)))
+
+
+def _ulp(x: torch.Tensor, dtype) -> torch.Tensor:
+    """Spacing of `dtype` at magnitude |x| (fp32 tensor in, fp32 out)."""
+    mant = 10 if dtype == torch.float16 else 7
+    e = torch.floor(torch.log2(x.abs().clamp(min=2.0 ** -14)))
+    return torch.exp2(e - mant)
+
+
+def _engine_kw(batch, dtype):
+    return dict(use_dummy=False, block_size=16, gpu_mem_utilization=0.9, num_cpu_blocks=0,
+                max_seqs_in_block_table=max(8, batch), max_blocks_per_seq=72, max_batch_size=batch,
+                max_tokens_in_batch=batch * 1040, dtype=dtype)
+
+
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_full_width_forward_matches_oracle(tmp_path, case, dtype):
+    from swiftllm_amd import EngineConfig, LlamaModel, LlamaModelConfig
+    lens, steps = CASES[case]
+    batch = len(lens)
+    tdtype = torch.float16 if dtype == "float16" else torch.bfloat16
+    cfg = synth.make_config(**CFG)
+    sd = synth.make_state_dict(cfg, seed=31, dtype=tdtype)
+    g = torch.Generator().manual_seed(8)
+    prompts = [torch.randint(0, cfg["vocab_size"], (n,), generator=g).tolist() for n in lens]
+    seq_ids = list(range(batch))
+    num_blocks = sum(-(-(n + steps + 1) // 16) for n in lens) + 4
+    kw = _engine_kw(batch, dtype)
+
+    # ---- the checker: oracle with exact scores (teacher), and with the reference kernel's score rounding ----
+    def run_oracle(score_dtype, forced=None):
+        ref = RefLlamaModel(LlamaModelConfig(cfg), EngineConfig(model_path="", **kw), sd, tdtype, score_dtype=score_dtype)
+        ref.init_kvcache_and_swap(num_blocks)
+        toks, logits = [ref.forward(prompts, seq_ids, [])], [ref.last_logits.clone()]
+        cur = list(lens)
+        for s in range(steps):
+            cur = [n + 1 for n in cur]
+            feed = forced[s] if forced is not None else toks[-1]
+            toks.append(ref.forward([[t] for t in feed], seq_ids, list(cur)))
+            logits.append(ref.last_logits.clone())
+        return toks, logits
+
+    want_toks, want_logits = run_oracle("fp32")
+    noise_toks, noise_logits = run_oracle("ref", forced=want_toks)
+
+    # ---- the product ---------------------------------------------------------------------------------------
+    synth.write_model_dir(str(tmp_path), cfg, sd)
+
+    def run_hip(opts):
+        model = LlamaModel(EngineConfig(model_path=str(tmp_path), **kw, **opts))
+        model.load_weights()
+        model.init_kvcache_and_swap(num_blocks)
+        model.post_layer.logits_tap = []
+        tap = model.post_layer.logits_tap
+        toks, logits = [model.forward(prompts, seq_ids, [])], [tap[-1].float().cpu()]
+        cur = list(lens)
+        for s in range(steps):
+            cur = [n + 1 for n in cur]
+            toks.append(model.forward([[t] for t in want_toks[s]], seq_ids, list(cur)))   # teacher-forced
+            logits.append(tap[-1].float().cpu())
+        del model
+        torch.cuda.empty_cache()
+        return toks, logits
+
+    def compare(toks, logits):
+        """per step: max |dlogit|, the same in ulps of the row scale, token mismatches and whether each mismatch
+        sits on a near-tie of the teacher"""
+        rows = []
+        for s, (a, b) in enumerate(zip(logits, want_logits)):
+            d = (a - b).abs()
+            row_ulp = _ulp(b.abs().amax(dim=1, keepdim=True), tdtype)
+            mism = [i for i, (x, y) in enumerate(zip(toks[s], want_toks[s])) if x != y]
+            ties = []
+            for i in mism:
+                top2 = b[i].topk(2).values
+                ties.append(float(top2[0] - top2[1]))
+            rows.append(dict(step=s, max_abs=float(d.max()), max_ulp_of_row=float((d / row_ulp).max()),
+                             mismatches=len(mism), mismatch_top2_gaps=ties))
+        return rows
+
+    report = dict(case=case, dtype=dtype, batch=batch, decode_steps=steps, model=CFG,
+                  noise_floor_ref_scores_vs_exact=compare(noise_toks, noise_logits))
+    failures = []
+    for name, opts in VARIANTS:
+        toks, logits = run_hip(opts)
+        rows = compare(toks, logits)
+        report[name] = rows
+        worst_abs = max(r["max_abs"] for r in rows)
+        worst_ulp = max(r["max_ulp_of_row"] for r in rows)
+        if worst_ulp > 2.0:
+            failures.append(f"{name}: logits off by {worst_ulp:.2f} ulp of the row scale ({worst_abs:.2e} abs)")
+        for r in rows:
+            for gap in r["mismatch_top2_gaps"]:
+                if gap > 2 * worst_abs:
+                    failures.append(f"{name}: token mismatch at step {r['step']} with oracle top-2 gap {gap:.2e} "
+                                    f"> 2 x logit distance {worst_abs:.2e}")
+    def summarise(rows):
+        return dict(max_abs=max(r["max_abs"] for r in rows), max_ulp_of_row=max(r["max_ulp_of_row"] for r in rows),
+                    token_mismatches=sum(r["mismatches"] for r in rows),
+                    tokens_compared=(steps + 1) * batch)
+    report["summary"] = {k: summarise(v) for k, v in report.items() if isinstance(v, list)}
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, f"parity_fullwidth_{case}_{dtype}.json"), "w", encoding="utf-8") as f:
+        json.dump(report, f, indent=1)
+    print("\n[full-width parity]", case, dtype, json.dumps(report["summary"]))
+    assert not failures, failures
+
+
+@pytest.mark.parametrize("name", ["scalar1", "scalar4", "dict"])
+def test_product_rope_tables_match_reference_golden(tmp_path, golden, name):
+    """a10: the PRODUCT's device-evaluated cos/sin tables (LlamaModel._init_to_get_rotary), incl. scalar > 1 and
+    dict-style rope_scaling, against rows frozen from the reference's own _init_to_get_rotary (model.py:177-225).
+    Device trig (fp32) may differ from the CPU's by an fp32 ulp before the fp16 rounding: <= 1 fp16 ulp, and the
+    table length must be identical."""
+    from tests.conftest import ulp_diff_fp16
+    from swiftllm_amd import EngineConfig, LlamaModel
+    g = golden("rope_tables.pt")[name]
+    cfg = synth.make_config(num_hidden_layers=1, hidden_size=4 * g["head_dim"], num_attention_heads=4,
+                            num_key_value_heads=2, intermediate_size=256, vocab_size=64,
+                            max_position_embeddings=g["max_position_embeddings"], rope_theta=g["rope_theta"],
+                            rope_scaling=g["rope_scaling"])
+    synth.write_model_dir(str(tmp_path), cfg)
+    model = LlamaModel(EngineConfig(model_path=str(tmp_path), use_dummy=True, block_size=16, gpu_mem_utilization=0.5,
+                                    num_cpu_blocks=0, max_seqs_in_block_table=4, max_blocks_per_seq=8,
+                                    max_batch_size=2, max_tokens_in_batch=64))
+    model.load_weights()
+    assert model._cos_cached.shape == (g["num_rows"], g["head_dim"] // 2)
+    assert model._sin_cached.shape == (g["num_rows"], g["head_dim"] // 2)
+    rows = g["rows"].long()
+    cos = model._cos_cached[rows.cuda()].cpu()
+    sin = model._sin_cached[rows.cuda()].cpu()
+    assert cos.dtype == torch.float16
+    # |x| near 0 crosses many fp16 binades: compare in absolute terms there, in ulps elsewhere
+    for got, want in ((cos, g["cos"]), (sin, g["sin"])):
+        big = want.abs() >= 2.0 ** -6
+        assert ulp_diff_fp16(torch.where(big, got, want), want) <= 1
+        assert (got.float() - want.float()).abs().max().item() <= 2.0 ** -11

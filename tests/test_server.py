@@ -192,6 +192,17 @@ def test_api_server_generate_endpoint():
         assert client.get("/load").json() == {"outstanding_tokens": 0}
         r = client.post("/generate", json={"prompt_token_ids": list(range(200)), "output_len": 3})
         assert r.status_code == 400 and "max_tokens_in_batch" in r.json()["error"]
+        # malformed bodies are answered 400 and never reach the engine (which dies on any exception)
+        for body in ({"prompt_token_ids": [1, 2]}, {"prompt_token_ids": [1, 2], "output_len": "3"},
+                     {"prompt_token_ids": [1, "x"], "output_len": 3}, {"prompt_token_ids": [1, -5], "output_len": 3},
+                     {"prompt_token_ids": [1, 2 ** 40], "output_len": 3}, {"prompt_token_ids": "12", "output_len": 3},
+                     {"prompt": 17, "output_len": 3}, [1, 2, 3]):
+            r = client.post("/generate", json=body)
+            assert r.status_code == 400 and "error" in r.json(), body
+        r = client.post("/generate", content=b"{not json", headers={"content-type": "application/json"})
+        assert r.status_code == 400
+        r = client.post("/generate", json={"prompt_token_ids": [4, 5], "output_len": 3})
+        assert r.status_code == 200 and r.json() == {"output_token_ids": _expected([4, 5], 3)}  # still alive
 
 
 def test_replica_router_balances_by_outstanding_tokens():
@@ -212,6 +223,15 @@ def test_unservable_requests_are_rejected_not_queued():
     assert "max_blocks_per_seq" in s.why_unservable(_req(60, 100))        # 160 tokens = 10 blocks > 8
     assert "pool" in s.why_unservable(_req(60, 45))                        # 105 tokens = 7 blocks > 6 in the pool
     assert "empty" in s.why_unservable(_req(0, 4))
+    # limits of the data plane: vocabulary (ids index the embedding table on the device) and rotary positions
+    # (LlamaModel.forward raises past the table: one long request must not take the replica down)
+    s.vocab_size, s.max_seq_len = 50, 40
+    assert s.why_unservable(_req(10, 4)) is None
+    assert "rotary" in s.why_unservable(_req(30, 11))
+    bad_id = _req(3, 2)
+    bad_id.prompt_token_ids = [1, 50, 2]
+    assert "prompt_token_ids" in s.why_unservable(bad_id)
+    s.vocab_size = s.max_seq_len = None
 
     async def run():
         model = FakeModel()

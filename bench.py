@@ -5,21 +5,30 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[2]): Llama-3-8B, bf16, random-init weights, batch 32 per GPU,
-1024-token synthetic prompts, 128 generated tokens. One "step" = one decode forward of the whole
-batch (`LlamaModel.forward`, the hot path) with everything resident in HBM. The prompt phase (one
-32x1024-token prefill forward) runs before the timed region and is reported separately as
-`prefill_tok_s`. `value` = decode tokens/s of the whole job = n_gpus * batch * K / max-over-ranks
-time of the K timed steps (request-sharded replicas, weak scaling, no collective on the data path).
+Workload (BASELINE.json configs[2]): Llama-3-8B, bf16, random-init weights, batch 32 per GPU, 1024-token synthetic
+prompts, 128 generated tokens. One "step" = one decode forward of the whole batch (`LlamaModel.forward`, the hot
+path) with everything resident in HBM. The K timed steps always sit in the MIDDLE of the 128-token generation —
+contexts 1025 + (128-K)/2 ... whatever --steps is, so their mean context is the mean context of a full
+1024-in/128-out run (1088.5) and `value` is on the workload the config names, not on a lighter one: after the real
+prefill the sequences are advanced to the first warm-up context directly (their KV slots for the skipped positions
+hold the N(0,1) data the pool was filled with). The prompt phase (one 32x1024-token prefill forward) runs before
+the timed region and is reported separately as `prefill_tok_s`. `value` = decode tokens/s of the whole job =
+n_gpus * batch * K / max-over-ranks time of the K timed steps (request-sharded replicas, weak scaling, no
+collective on the data path). Each rank pins itself to the NUMA-local cores of its GPU.
 
 Extra objects on the JSON line:
-  roofline      the dominant hand-written kernel of the decode step (paged-attention phase 1):
-                algorithmic bytes per launch / its mean launch duration, measured live with HIP events
-                on the launch stream over launches that cycle through all layers' KV (4.6 GB, far
-                past the 256 MiB Infinity Cache), at the decode loop's exact shapes and geometry.
-  step_roofline the whole decode step against HBM: (weights + KV read + KV write) / step time.
-  cpu_baseline  rank 0, N=1 only: the CPU oracle's forward (oracle/ref_model.py — the reference has
-                no CPU path of its own) on the host cores, on a bounded sample.
+  roofline        the kernel with the largest share of the decode step, timed live with HIP events on the launch
+                  stream over launches that cycle through all layers' weights / KV (far past the 256 MiB Infinity
+                  Cache), at the decode loop's exact entry point, shapes and launch geometry: algorithmic bytes per
+                  launch / mean launch duration. The other heavyweight rides along (roofline_paged_attention /
+                  roofline_up_gate_gemm). The attention entry is swl_paged_attn_decode_qkv fed by real split-K slabs —
+                  the variant the step runs.
+  step_roofline   the whole decode step against HBM: (weights + KV read + KV write) / step time.
+  eager           the same K steps with hipGraph replay off (the product default), next to the replayed `value`.
+  configs1_batch1 / configs3_llama2_7b_4x16k   (rank 0, N=1) short driver-measured runs of BASELINE configs[1]
+                  and configs[3] (KV pre-filled, no 16k prefill).
+  cpu_baseline    rank 0, N=1 only: the CPU oracle's forward (oracle/ref_model.py — the reference has no CPU path
+                  of its own) on the host cores, on a bounded sample.
 """
 import argparse
 import json
@@ -27,9 +36,6 @@ import os
 import sys
 import tempfile
 import time
-import types
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -37,15 +43,17 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 HBM_COPY_GBS = 6290.0
+GEN_LEN = 128               # BASELINE.json configs[2]: 1024-in / 128-out
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=120)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=32, help="sequences per GPU")
     ap.add_argument("--prompt-len", type=int, default=1024)
+    ap.add_argument("--gen-len", type=int, default=GEN_LEN)
     ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama2-7b", "tiny"])
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float16"])
     ap.add_argument("--no-hip-graph", action="store_true")
@@ -56,6 +64,8 @@ def parse_args():
                     help="fold norm/rotary/residual hand-offs into the GEMMs (experimental, slower: DESIGN.md §4.4)")
     ap.add_argument("--no-packed-weights", dest="packed_weights", action="store_false")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the configs[1] / configs[3] / eager side runs")
+    ap.add_argument("--skip-prefill", action="store_true", help="fill the KV pool directly instead of running the prompt")
     ap.add_argument("--kernel-iters", type=int, default=256)
     return ap.parse_args()
 
@@ -88,16 +98,17 @@ def ensure_positions(cfg, needed):
     return cfg
 
 
-def build_model(args, cfg, num_blocks):
+def build_model(args, cfg, num_blocks, batch, max_len, hip_graph):
+    import torch
     from swiftllm_amd import EngineConfig, LlamaModel
     path = tempfile.mkdtemp(prefix="swl_bench_")
     with open(os.path.join(path, "config.json"), "w", encoding="utf-8") as f:
         json.dump(cfg, f)
     ec = EngineConfig(model_path=path, use_dummy=True, block_size=16, gpu_mem_utilization=0.97,
-                      num_cpu_blocks=0, max_seqs_in_block_table=max(64, args.batch),
-                      max_blocks_per_seq=max(256, (args.prompt_len + args.steps + args.warmup) // 16 + 8),
-                      max_batch_size=args.batch, max_tokens_in_batch=args.batch * args.prompt_len,
-                      dtype=args.dtype, fuse_qkv=args.fuse_qkv, use_hip_graph=not args.no_hip_graph,
+                      num_cpu_blocks=0, max_seqs_in_block_table=max(64, batch),
+                      max_blocks_per_seq=max(256, max_len // 16 + 8),
+                      max_batch_size=batch, max_tokens_in_batch=batch * min(max_len, 8192),
+                      dtype=args.dtype, fuse_qkv=args.fuse_qkv, use_hip_graph=hip_graph,
                       use_skinny_gemm=args.skinny_gemm, fuse_splitk_consumers=args.splitk_fusion,
                       fuse_decode_layer=getattr(args, "layer_fusion", False),
                       pack_decode_weights=getattr(args, "packed_weights", True))
@@ -118,10 +129,14 @@ def build_model(args, cfg, num_blocks):
                 t.normal_(0.0, 0.02, generator=g)
     model.repack_decode_weights()       # the packed decode copies follow the re-initialised weights
     model.init_kvcache_and_swap(num_blocks)
+    with torch.inference_mode():        # positions the bench skips over must hold data, not zeros (DVFS: §5.4 rule 25)
+        model.k_cache.normal_(0.0, 1.0, generator=g)
+        model.v_cache.normal_(0.0, 1.0, generator=g)
     return model
 
 
 def timed(fn):
+    import torch
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = fn()
@@ -136,67 +151,152 @@ def weight_bytes(cfg, e):
     return e * (L * (2 * h * h + 2 * kvd * h + 3 * I * h + 2 * h) + V * h + h)
 
 
-def kernel_roofline(model, lens, iters):
-    """Mean duration of paged-attention phase 1 (the dominant hand-written kernel of a decode step)
-    measured with HIP events on the launch stream, at the decode loop's shapes and launch geometry."""
+def kv_token_bytes(cfg, e):
+    return 2 * cfg["num_hidden_layers"] * cfg["num_key_value_heads"] * (cfg["hidden_size"] // cfg["num_attention_heads"]) * e
+
+
+def step_roofline(cfg, e, batch, mean_ctx, ms_per_step):
+    W = weight_bytes(cfg, e)
+    kvt = kv_token_bytes(cfg, e)
+    step_bytes = W + batch * mean_ctx * kvt + batch * kvt
+    gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy": round(gbs / HBM_COPY_GBS, 4),
+            "bytes_per_step": int(step_bytes), "weights_bytes": int(W), "kv_bytes": int(step_bytes - W)}
+
+
+class DecodeRun:
+    """`batch` sequences decoding in lock step on one model; contexts can be set directly (block allocation follows)."""
+
+    def __init__(self, model, batch, vocab, seed):
+        import torch
+        self.model, self.batch = model, batch
+        self.seq_ids = list(range(batch))
+        g = torch.Generator().manual_seed(seed)
+        self.toks = torch.randint(0, vocab, (batch,), generator=g).tolist()
+        self.lens = [0] * batch
+
+    def prefill(self, prompts):
+        self.toks = self.model.forward(prompts, self.seq_ids, [])
+        self.lens = [len(p) for p in prompts]
+        return self.toks
+
+    def jump_to(self, context):
+        """Next step decodes at `context` (= length including the new token)."""
+        assert all(context - 1 >= n for n in self.lens)
+        self.lens = [context - 1] * self.batch
+
+    def step(self):
+        self.lens = [n + 1 for n in self.lens]
+        self.toks = self.model.forward([[t] for t in self.toks], self.seq_ids, self.lens)
+
+    def timed_steps(self, warmup, steps, barrier=lambda: None):
+        import torch
+        for _ in range(warmup):
+            self.step()
+        first = self.lens[0] + 1
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        barrier()
+        return dt, first, self.lens[0]
+
+    def release(self):
+        self.model.free_seqs_resources(self.seq_ids)
+        self.lens = [0] * self.batch
+
+
+def _event_time(launch, iters, warm):
+    import torch
+    for i in range(warm):
+        launch(i)
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    start.record()
+    for i in range(iters):
+        launch(i)
+    stop.record()
+    stop.synchronize()
+    return start.elapsed_time(stop) * 1e3 / iters
+
+
+def _pmc_traffic(name, alg_bytes, ok):
+    """HBM traffic cannot be read from inside this process: it comes from the committed rocprofv3 PMC passes on this
+    kernel (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/*.json), scaled by bytes to this launch; null for
+    a kernel specialisation that was not profiled."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not ok or not os.path.exists(path):
+        return None, None
+    with open(path, encoding="utf-8") as f:
+        pmc = json.load(f)
+    return int(alg_bytes * pmc["traffic_over_algorithmic"]), f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, scaled by bytes)"
+
+
+def attention_roofline(model, lens, iters):
+    """Mean duration of the decode step's attention launch: swl_paged_attn_decode_qkv (rotary + KV store in its
+    prologue) fed by the split-K slabs of a real fused-qkv projection, at the decode loop's shapes and launch
+    geometry, HIP events on the launch stream, cycling through all layers' KV. Falls back to the plain
+    swl_paged_attn_decode entry when the decode path does not use the slab-fed variant."""
+    import torch
     from swiftllm_amd import _hip
     from swiftllm_amd.worker.batch_plan import plan_batch
+    from swiftllm_amd.worker.kernels.linear import SplitKPartials, linear_splitk
+    from swiftllm_amd.worker.kernels.paged_attn import paged_attention, paged_attention_from_qkv_splitk
+    import types
     mc, ecfg = model.model_config, model.engine_config
     B, H, KVH, D, L = len(lens), mc.num_q_heads, mc.num_kv_heads, mc.head_dim, mc.num_layers
     plan = plan_batch([[0]] * B, list(range(B)), lens, KVH, model._num_slots)
     sbs, nsb = model._graph_bucket(plan) if ecfg.use_hip_graph else (plan.seq_block_size, plan.num_seq_blocks)
     dev = model.device
-    q = torch.randn(B, H, D, device=dev, dtype=torch.float32).to(model.dtype)
-    o = torch.empty_like(q)
-    seq_ids = torch.arange(B, dtype=torch.int32, device=dev)
-    d_lens = torch.tensor(lens, dtype=torch.int32, device=dev)
-    mid_o = torch.empty(B * H * nsb * D, dtype=torch.float32, device=dev)
-    mid_lse = torch.empty(B * H * nsb, dtype=torch.float32, device=dev)
     bt = model.gpu_block_manager.block_table
-    code, scale = _hip.dtype_code(model.dtype), D ** -0.5
+    st = types.SimpleNamespace(
+        num_decoding_seqs=B, num_prefill_seqs=0, seq_block_size=sbs, num_seq_blocks=nsb, softmax_scale=D ** -0.5,
+        decoding_seq_lens=torch.tensor(lens, dtype=torch.int32, device=dev),
+        seq_ids=torch.arange(B, dtype=torch.int32, device=dev), position_cos=model._cos_cached,
+        position_sin=model._sin_cached, position_indices=torch.tensor([n - 1 for n in lens], dtype=torch.int32, device=dev),
+        paged_attn_scratch=torch.empty(_hip.scratch_bytes(B, H, D, nsb) // 4 + 4, dtype=torch.float32, device=dev))
+    o = torch.empty(B, H, D, device=dev, dtype=model.dtype)
+    x = torch.randn(B, mc.hidden_size, device=dev, dtype=torch.float32).to(model.dtype)
+    w_qkv = getattr(model.weight.layers[0], "qkv_proj", None)
+    slab_fed = (w_qkv is not None and getattr(ecfg, "use_skinny_gemm", False) and getattr(ecfg, "fuse_splitk_consumers", True)
+                and getattr(ecfg, "fuse_rope_into_attention", True) and D in (32, 64, 128))
+    part = linear_splitk(x, w_qkv, always=True) if slab_fed else None
+    if isinstance(part, SplitKPartials):
+        part = SplitKPartials(part.slabs[:part.k_splits * B * part.shape[1]].clone(), part.k_splits, B, part.shape[1], part.dtype)
+        entry = "swl_paged_attn_decode_qkv (paged_attn_phase1_kernel<QKV>: rotary + KV store + attention)"
 
-    def launch(layer):
-        _hip.call("swl_paged_attn_phase1", o.data_ptr(), q.data_ptr(), model.k_cache.data_ptr(),
-                  model.v_cache.data_ptr(), bt.data_ptr(), seq_ids.data_ptr(), d_lens.data_ptr(),
-                  mid_o.data_ptr(), mid_lse.data_ptr(), scale, B, H, KVH, D, L, ecfg.block_size, layer,
-                  bt.shape[1], sbs, nsb, H * D, H * D, code, _hip.stream())
+        def launch(i):
+            paged_attention_from_qkv_splitk(part, model.k_cache, model.v_cache, bt, mc, ecfg, st, i % L, o)
+    else:
+        q = torch.randn(B, H, D, device=dev, dtype=torch.float32).to(model.dtype)
+        entry = "swl_paged_attn_decode (paged_attn_phase1_kernel)"
 
-    for i in range(min(iters, 2 * L)):
-        launch(i % L)
-    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    start.record()
-    for i in range(iters):
-        launch(i % L)
-    stop.record()
-    stop.synchronize()
-    us = start.elapsed_time(stop) * 1e3 / iters
+        def launch(i):
+            paged_attention(q, model.k_cache, model.v_cache, bt, mc, ecfg, st, i % L, o)
+    us = _event_time(launch, iters, min(iters, 2 * L))
     e = model.dtype.itemsize
     kv_bytes = sum(lens) * 2 * KVH * D * e
     splits = sum(-(-n // sbs) for n in lens)
-    part_bytes = (splits * H * (D + 1) * 4) if nsb > 1 else B * H * D * e
-    alg_bytes = kv_bytes + B * H * D * e + part_bytes
+    part_bytes = (2 * splits * H * (D + 1) * 4) if nsb > 1 else 0
+    slab_bytes = part.k_splits * B * part.shape[1] * 4 if isinstance(part, SplitKPartials) else B * H * D * e
+    alg_bytes = kv_bytes + slab_bytes + B * H * D * e + part_bytes
     gbs = alg_bytes / (us * 1e-6) / 1e9
-    # HBM traffic cannot be read from inside this process: it comes from the committed rocprofv3 PMC
-    # passes on this kernel (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/r01_paged_attn_pmc.*),
-    # scaled by bytes to this launch; null for a kernel specialisation that was not profiled.
-    traffic, src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_paged_attn_pmc.json")
-    if os.path.exists(pmc_path) and (H, KVH, D) == (32, 8, 128) and nsb == 1:
-        with open(pmc_path, encoding="utf-8") as f:
-            pmc = json.load(f)
-        traffic = int(alg_bytes * pmc["traffic_over_algorithmic"])
-        src = "profiles/r01_paged_attn_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, scaled by bytes)"
-    return dict(bound="hbm", kernel="paged_attn_phase1_kernel", achieved=round(gbs, 1), peak=HBM_PEAK_GBS,
-                unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), frac_of_measured_copy=round(gbs / HBM_COPY_GBS, 4),
+    traffic, src = _pmc_traffic("r01_paged_attn_pmc.json", alg_bytes, (H, KVH, D) == (32, 8, 128) and nsb == 1)
+    return dict(bound="hbm", kernel=entry, achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(gbs / HBM_PEAK_GBS, 4), frac_of_measured_copy=round(gbs / HBM_COPY_GBS, 4),
                 traffic=traffic, traffic_source=src, bytes_per_launch=int(alg_bytes), us_per_launch=round(us, 2),
                 seq_block_size=sbs, num_seq_blocks=nsb, launches=iters)
 
 
 def gemm_roofline(model, batch, iters):
-    """Mean duration of the up/gate projection + SiLU-gate (the kernel with the largest share of a decode step:
-    54 % of the weight bytes), HIP events on the launch stream, cycling through all layers' weights
-    (7.5 GB footprint >> the 256 MiB Infinity Cache). None when the decode path does not use it."""
+    """Mean duration of the up/gate projection + SiLU-gate (54 % of the weight bytes of a decode step), HIP events on
+    the launch stream, cycling through all layers' weights (7.5 GB footprint >> the 256 MiB Infinity Cache). None
+    when the decode path does not use it."""
+    import torch
     from swiftllm_amd import _hip
     mc, ecfg = model.model_config, model.engine_config
     M, K, I = batch, mc.hidden_size, mc.ffn_inter_dim
@@ -206,35 +306,19 @@ def gemm_roofline(model, batch, iters):
     x = torch.randn(M, K, device=model.device, dtype=torch.float32).to(model.dtype)
     out = torch.empty(M, I, device=model.device, dtype=model.dtype)
     code = _hip.dtype_code(model.dtype)
-
     packed = all(getattr(l.up_gate_proj, "_swl_packed", None) is not None for l in layers)
     fn = "swl_gemm_skinny_packed_silu_gate" if packed else "swl_gemm_skinny_silu_gate"
     srcs = [(l.up_gate_proj._swl_packed if packed else l.up_gate_proj) for l in layers]
 
     def launch(i):
         _hip.call(fn, out.data_ptr(), x.data_ptr(), srcs[i % len(srcs)].data_ptr(), M, I, K, K, I, code, _hip.stream())
-    for i in range(min(iters, len(layers))):
-        launch(i)
-    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    start.record()
-    for i in range(iters):
-        launch(i)
-    stop.record()
-    stop.synchronize()
-    us = start.elapsed_time(stop) * 1e3 / iters
+    us = _event_time(launch, iters, min(iters, len(layers)))
     e = model.dtype.itemsize
     alg_bytes = 2 * I * K * e + M * K * e + M * I * e
     gbs = alg_bytes / (us * 1e-6) / 1e9
-    traffic, src = None, None
     pmc_name = "r01f_gemm_silu_packed_pmc.json" if packed else "r01e_gemm_silu_pmc.json"
-    pmc_path = os.path.join(ROOT, "profiles", pmc_name)
-    if os.path.exists(pmc_path) and (I, K) == (14336, 4096) and model.dtype == torch.bfloat16:
-        with open(pmc_path, encoding="utf-8") as f:
-            pmc = json.load(f)
-        traffic = int(alg_bytes * pmc["traffic_over_algorithmic"])
-        src = f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, scaled by bytes)"
-    return dict(bound="hbm", kernel="gemm_skinny_ring_kernel<SiluGate%s> (up/gate projection + SiLU-gate)" % (", packed W" if packed else ""),
+    traffic, src = _pmc_traffic(pmc_name, alg_bytes, (I, K) == (14336, 4096) and model.dtype == torch.bfloat16)
+    return dict(bound="hbm", kernel="%s (gemm_skinny_ring_kernel<SiluGate%s>: up/gate projection + SiLU-gate)" % (fn, ", packed W" if packed else ""),
                 achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
                 frac_of_measured_copy=round(gbs / HBM_COPY_GBS, 4), traffic=traffic, traffic_source=src,
                 bytes_per_launch=int(alg_bytes), us_per_launch=round(us, 2), launches=iters)
@@ -245,6 +329,7 @@ def cpu_baseline(cfg, batch, context, dtype):
     and batch, truncated to 2 of the layers, short context, a couple of decode steps (~10-30 s incl.
     building the random weights); per-layer and head costs are timed separately and recombined for
     the full depth. This is the ONLY part of bench.py that touches oracle/."""
+    import torch
     from oracle import eager_ops, synth
     from oracle.ref_model import RefLlamaModel
     from swiftllm_amd import EngineConfig, LlamaModelConfig
@@ -286,90 +371,111 @@ def cpu_baseline(cfg, batch, context, dtype):
                         f"{steps} steps, native 16-bit CPU GEMM"))
 
 
+def side_run(args, model_name, batch, context, steps, warmup, label, model=None):
+    """A short decode-only measurement of another BASELINE config: KV for `context - warmup - 1` positions is taken
+    as it lies in the (N(0,1)-filled) pool, `warmup` + `steps` decode forwards run from there."""
+    import torch
+    cfg = ensure_positions(model_config_dict(model_name), context + steps + warmup + 2)
+    e = 2
+    own = model is None
+    if own:
+        max_len = context + steps + warmup + 2
+        num_blocks = batch * (-(-max_len // 16) + 1) + 8
+        model = build_model(args, cfg, num_blocks, batch, max_len, not args.no_hip_graph)
+    run = DecodeRun(model, batch, cfg["vocab_size"], seed=7)
+    run.jump_to(context - (steps // 2) - warmup)
+    dt, first, last = run.timed_steps(warmup, steps)
+    run.release()
+    ms = dt / steps * 1e3
+    out = dict(workload=label, model=model_name, batch=batch, context_first=first, context_last=last, steps=steps,
+               warmup=warmup, ms_per_step=round(ms, 4), decode_tok_s=round(batch * steps / dt, 1),
+               hip_graph=bool(model.engine_config.use_hip_graph),
+               step_roofline=step_roofline(cfg, e, batch, (first + last) / 2, ms))
+    if own:
+        del run, model
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse_args()
     from swiftllm_amd import dp
     rank, local_rank, world = dp.env_rank_world()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    # one GPU per process, seen as device 0 (SURVEY.md §8e), unless the launcher already restricted visibility
+    vis = [k for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES") if os.environ.get(k)]
+    if world > 1 and not vis:
+        os.environ["HIP_VISIBLE_DEVICES"] = str(local_rank)
+    import torch
+    ndev = max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(0 if (world > 1 and not vis and ndev == 1) else local_rank % ndev)
+    pinned = dp.pin_to_local_cores(local_rank, local_world) if world > 1 else []
     dp.init_control_group()
 
     cfg = model_config_dict(args.model)
-    B, S = args.batch, args.prompt_len
-    gen_total = args.warmup + args.steps
-    ensure_positions(cfg, S + gen_total)
-    blocks_per_seq = (S + gen_total + 1 + 15) // 16
+    B, S, GEN = args.batch, args.prompt_len, args.gen_len
+    K, Wm = args.steps, args.warmup
+    # timed contexts: K consecutive steps centred in the GEN-token generation (all of it and beyond when K >= GEN)
+    first_timed = S + 1 + max(0, (GEN - K) // 2)
+    last_needed = max(S + GEN, first_timed + K)
+    ensure_positions(cfg, last_needed + 2)
+    blocks_per_seq = -(-(last_needed + 2) // 16)
     num_blocks = int(B * blocks_per_seq * 1.25) + 8
-    model = build_model(args, cfg, num_blocks)
+    model = build_model(args, cfg, num_blocks, B, last_needed + 2, not args.no_hip_graph)
     e = model.dtype.itemsize
 
     # every rank serves its own shard of the requests: `batch` sequences per GPU
     g = torch.Generator().manual_seed(1 + rank)
     prompts = [torch.randint(0, cfg["vocab_size"], (S,), generator=g).tolist() for _ in range(B)]
-    seq_ids = list(range(B))
+    run = DecodeRun(model, B, cfg["vocab_size"], seed=1 + rank)
 
     # ---- prompt phase (reported, outside the K timed steps) ------------------------------------------------
-    model.forward(prompts, seq_ids, [])                 # untimed: GEMM heuristics, allocator pools
-    model.free_seqs_resources(seq_ids)
-    dp.barrier()
-    toks, prefill_s = timed(lambda: model.forward(prompts, seq_ids, []))
-    prefill_units, prefill_max_s = dp.reduce_job(B * S, prefill_s)
+    prefill_units = prefill_max_s = None
+    if not args.skip_prefill:
+        run.prefill(prompts)                            # untimed: GEMM heuristics, allocator pools
+        run.release()
+        dp.barrier()
+        _, prefill_s = timed(lambda: run.prefill(prompts))
+        prefill_units, prefill_max_s = dp.reduce_job(B * S, prefill_s)
+    else:
+        run.lens = [S] * B
 
-    # ---- decode: W warm-up steps, then exactly K timed steps --------------------------------------------------
-    lens = [S] * B
-
-    def step():
-        nonlocal toks, lens
-        lens = [n + 1 for n in lens]
-        toks = model.forward([[t] for t in toks], seq_ids, lens)
-
-    for _ in range(args.warmup):
-        step()
-    first_ctx = lens[0] + 1
-    dp.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    local_s = time.perf_counter() - t0
-    dp.barrier()
-    units, max_s = dp.reduce_job(B * args.steps, local_s)
-    last_ctx = lens[0]
+    # ---- decode: W warm-up steps, then exactly K timed steps, centred in the generation --------------------------
+    run.jump_to(max(S + 1, first_timed - Wm))
+    local_s, first_ctx, last_ctx = run.timed_steps(Wm, K, dp.barrier)
+    units, max_s = dp.reduce_job(B * K, local_s)
+    graphs = len(getattr(model, "_decode_graphs", {}))
 
     if rank != 0:
         return
-    ms_per_step = max_s / args.steps * 1e3
+    ms_per_step = max_s / K * 1e3
     mean_ctx = (first_ctx + last_ctx) / 2
-    W = weight_bytes(cfg, e)
-    kv_token = 2 * cfg["num_hidden_layers"] * cfg["num_key_value_heads"] * (cfg["hidden_size"] // cfg["num_attention_heads"]) * e
-    step_bytes = W + B * mean_ctx * kv_token + B * kv_token
-    step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
     result = {
-        "metric": f"decode tok/s ({args.model} {args.dtype}, batch {B}/GPU, {S}-in/{gen_total}-out; prefill tok/s alongside)",
-        "value": round(units / max_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "metric": f"decode tok/s ({args.model} {args.dtype}, batch {B}/GPU, {S}-in/{GEN}-out; prefill tok/s alongside)",
+        "value": round(units / max_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": K,
+        "warmup": Wm, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype == "bfloat16" else "f16",
         "data": "synthetic (random-init weights, uniform random prompt ids)",
         "config": {"workload": f"BASELINE.json configs[2]: {args.model}, batch {B} per GPU, {S}-token prompts, "
-                               f"{gen_total} generated tokens (prefill forward, then decode forwards; "
-                               f"context {first_ctx}..{last_ctx} in the timed steps)",
-                   "global_batch": B * world, "prompt_len": S, "gen_len": gen_total,
+                               f"{GEN} generated tokens; the {K} timed decode forwards run at contexts "
+                               f"{first_ctx}..{last_ctx} (centred in the generation: mean context {mean_ctx:.1f} vs "
+                               f"{S + (GEN + 1) / 2:.1f} for all {GEN} tokens)",
+                   "global_batch": B * world, "prompt_len": S, "gen_len": GEN,
+                   "timed_contexts": [first_ctx, last_ctx],
                    "parallelism": f"request-sharded dp{world} (independent replicas, no collective)",
                    "hip_graph": not args.no_hip_graph, "fuse_qkv": args.fuse_qkv,
                    "skinny_gemm": args.skinny_gemm, "packed_decode_weights": getattr(args, "packed_weights", True),
-                   "kv_blocks": num_blocks, "decode_graphs_captured": len(getattr(model, "_decode_graphs", {}))},
-        "prefill_tok_s": round(prefill_units / prefill_max_s, 1),
-        "prefill_ms": round(prefill_max_s * 1e3, 2),
-        "step_roofline": {"bound": "hbm", "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": round(step_gbs / HBM_PEAK_GBS, 4),
-                          "frac_of_measured_copy": round(step_gbs / HBM_COPY_GBS, 4),
-                          "bytes_per_step": int(step_bytes), "weights_bytes": int(W),
-                          "kv_bytes": int(step_bytes - W)},
+                   "kv_blocks": num_blocks, "decode_graphs_captured": graphs,
+                   "cpu_affinity_cores": len(pinned) if pinned else None},
+        "step_roofline": step_roofline(cfg, e, B, mean_ctx, ms_per_step),
     }
+    if prefill_units is not None:
+        result["prefill_tok_s"] = round(prefill_units / prefill_max_s, 1)
+        result["prefill_ms"] = round(prefill_max_s * 1e3, 2)
     # `roofline` = the kernel with the largest share of the step; the other hand-written heavyweight next to it
-    attn = kernel_roofline(model, lens, args.kernel_iters)
+    attn = attention_roofline(model, run.lens, args.kernel_iters)
     gemm = gemm_roofline(model, B, args.kernel_iters)
     if gemm is not None and gemm["us_per_launch"] > attn["us_per_launch"]:
         result["roofline"], result["roofline_paged_attention"] = gemm, attn
@@ -377,9 +483,27 @@ def main():
         result["roofline"] = attn
         if gemm is not None:
             result["roofline_up_gate_gemm"] = gemm
+    if world == 1 and not args.no_extras:
+        # the same K steps with hipGraph replay off (EngineConfig's default), same contexts
+        if not args.no_hip_graph:
+            model.engine_config.use_hip_graph = False
+            run.release()
+            run.lens = [0] * B
+            run.jump_to(max(S + 1, first_timed - Wm))
+            dt, f2, l2 = run.timed_steps(Wm, K)
+            model.engine_config.use_hip_graph = True
+            result["eager"] = dict(ms_per_step=round(dt / K * 1e3, 4), value=round(B * K / dt, 1), contexts=[f2, l2],
+                                   note="hipGraph replay off: one HIP launch per kernel from Python")
+        run.release()
+        if args.model == "llama3-8b":
+            result["configs1_batch1"] = side_run(args, "llama3-8b", 1, 1024 + GEN // 2, 48, 8,
+                                                 "BASELINE.json configs[1]: batch 1 decode-only", model=model)
+    del run, model
+    torch.cuda.empty_cache()
+    if world == 1 and not args.no_extras and args.model == "llama3-8b":
+        result["configs3_llama2_7b_4x16k"] = side_run(args, "llama2-7b", 4, 16384, 24, 4,
+                                                      "BASELINE.json configs[3]: Llama-2-7B dims, batch 4, 16k context")
     if world == 1 and not args.no_cpu_baseline:
-        del model
-        torch.cuda.empty_cache()
         result["cpu_baseline"] = cpu_baseline(cfg, B, 16, args.dtype)
     print(json.dumps(result), flush=True)
 

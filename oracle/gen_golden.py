@@ -148,16 +148,7 @@ def gen_elementwise():
     _save("elementwise.pt", out)
 
 
-def _paged_setup(g, num_blocks, L, KVH, bs, D, seq_ids, lens, max_seqs=8, mbps=64):
-    """Random KV pool + a block table that scatters each sequence's blocks (non-monotonic ids)."""
-    k_cache = torch.randn(num_blocks, L, KVH, bs, D, generator=g).half()
-    v_cache = torch.randn(num_blocks, L, KVH, bs, D, generator=g).half()
-    perm = torch.randperm(num_blocks, generator=g).tolist()
-    block_table = torch.zeros(max_seqs, mbps, dtype=torch.int32)
-    for sid, ln in zip(seq_ids, lens):
-        for j in range((ln + bs - 1) // bs):
-            block_table[sid, j] = perm.pop()
-    return k_cache, v_cache, block_table
+from .synth import paged_setup as _paged_setup, seeded_paged_case  # noqa: E402
 
 
 def gen_paged_attention():
@@ -206,6 +197,31 @@ def gen_paged_attention():
                            v_cache=v_cache, block_table=bt, out=o, mid_o=mid_o, mid_lse=mid_lse)
         print("paged", name, "done")
     _save("paged_attention.pt", cases)
+
+
+def gen_paged_attention_real_geometry():
+    """Llama-3-8B head geometry at a configs[2]-sized context: 32 q / 8 kv heads of 128, contexts 1100 and 1024,
+    seq_block_size 256 (the reference's own choice at batch 32 x ~1k, model.py:305-324) -> 5 seq-blocks, phase 2
+    included. ~30 s in the interpreter. Inputs are NOT stored (9 MB): seed + checksum + outputs."""
+    from swiftllm.worker.kernels import paged_attn as pa
+    from swiftllm.model_config import LlamaModelConfig
+    from swiftllm.engine_config import EngineConfig
+    H, KVH, D, L, lens, sbs, seed, bs = 32, 8, 128, 1, [1100, 1024], 256, 1234, 16
+    seq_ids, k_cache, v_cache, bt, q, checksum = seeded_paged_case(seed, H, KVH, D, L, lens)
+    mc = LlamaModelConfig(dict(model_type="llama", hidden_act="silu", num_hidden_layers=L, num_attention_heads=H,
+                               num_key_value_heads=KVH, hidden_size=H * D, vocab_size=8, max_position_embeddings=2048,
+                               intermediate_size=16, rms_norm_eps=1e-5))
+    ec = EngineConfig(model_path="", use_dummy=True, block_size=bs, gpu_mem_utilization=0.9, num_cpu_blocks=0,
+                      max_seqs_in_block_table=bt.shape[0], max_blocks_per_seq=bt.shape[1], max_batch_size=8,
+                      max_tokens_in_batch=4096)
+    nsb = (max(lens) + sbs - 1) // sbs
+    st = _mk_state(num_decoding_seqs=len(lens), num_prefill_seqs=0, seq_block_size=sbs, num_seq_blocks=nsb,
+                   softmax_scale=D ** -0.5, decoding_seq_lens=torch.tensor(lens, dtype=torch.int32),
+                   seq_ids=torch.tensor(seq_ids, dtype=torch.int32))
+    o = torch.zeros(len(lens), H, D, dtype=torch.float16)
+    pa.paged_attention(q, k_cache, v_cache, bt, mc, ec, st, 0, o)
+    _save("paged_attention_llama3_1k.pt", dict(H=H, KVH=KVH, D=D, L=L, block_size=bs, layer=0, lens=lens, seq_ids=seq_ids,
+                                                seq_block_size=sbs, seed=seed, kv_checksum=checksum, q=q, out=o))
 
 
 def gen_prefill_attention():
@@ -398,7 +414,7 @@ def main():
     _install_harness()
     only = set(sys.argv[1:])
     for fn in (gen_elementwise, gen_kvcache_and_blocks, gen_rope_tables, gen_prefill_attention,
-               gen_paged_attention, gen_e2e):
+               gen_paged_attention, gen_paged_attention_real_geometry, gen_e2e):
         if not only or fn.__name__ in only:
             fn()
 

@@ -75,3 +75,27 @@ def write_model_dir(path: str, cfg: dict, state_dict: dict = None, fmt: str = "s
     else:
         torch.save(state_dict, os.path.join(path, "pytorch_model.bin"))
     return path
+
+
+def paged_setup(g, num_blocks, L, KVH, bs, D, seq_ids, lens, max_seqs=8, mbps=64):
+    """Random KV pool + a block table that scatters each sequence's blocks (non-monotonic ids)."""
+    k_cache = torch.randn(num_blocks, L, KVH, bs, D, generator=g).half()
+    v_cache = torch.randn(num_blocks, L, KVH, bs, D, generator=g).half()
+    perm = torch.randperm(num_blocks, generator=g).tolist()
+    block_table = torch.zeros(max_seqs, mbps, dtype=torch.int32)
+    for sid, ln in zip(seq_ids, lens):
+        for j in range((ln + bs - 1) // bs):
+            block_table[sid, j] = perm.pop()
+    return k_cache, v_cache, block_table
+
+
+def seeded_paged_case(seed, H, KVH, D, L, lens, bs=16, max_seqs=4, mbps=80):
+    """K/V pool, block table and q of a decode-attention case as a pure function of `seed` (CPU generator): large
+    cases are committed as seed + outputs only, tests regenerate the inputs and check `kv_checksum`."""
+    g = torch.Generator().manual_seed(seed)
+    seq_ids = list(range(1, 1 + len(lens)))
+    nblk = sum((n + bs - 1) // bs for n in lens) + 3
+    k_cache, v_cache, bt = paged_setup(g, nblk, L, KVH, bs, D, seq_ids, lens, max_seqs=max_seqs, mbps=mbps)
+    q = torch.randn(len(lens), H, D, generator=g).half()
+    checksum = float(k_cache.double().sum() + 3.0 * v_cache.double().sum() + 7.0 * bt.double().sum())
+    return seq_ids, k_cache, v_cache, bt, q, checksum

@@ -49,8 +49,18 @@ def _newer(target: str, deps) -> bool:
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force: bool = False, jobs: int = 0, verbose: bool = True) -> str:
+def build(force: bool = False, jobs: int = 0, verbose: bool = True, tag: str = "", defines=()) -> str:
+    """Build the library. `tag` + `defines` (-D macros) build an EXPERIMENT variant next to it
+    (libswiftllm_hip_<tag>.so, objects under build/<tag>/): tools/ select one with SWIFTLLM_HIP_LIB to A/B a
+    kernel parameter on the GPU box without touching the product library."""
     hipcc = _hipcc()
+    global OBJ_DIR, LIB
+    obj_dir = os.path.join(HERE, "build", tag) if tag else OBJ_DIR
+    lib = os.path.join(HERE, f"libswiftllm_hip_{tag}.so") if tag else LIB
+    return _build(hipcc, obj_dir, lib, [f"-D{d}" for d in defines], force, jobs, verbose)
+
+
+def _build(hipcc, OBJ_DIR, LIB, extra, force, jobs, verbose) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     hdrs = [h if os.path.isabs(h) else os.path.join(HERE, h) for h in HEADERS]
     hdrs.append(os.path.abspath(__file__))
@@ -64,7 +74,7 @@ def build(force: bool = False, jobs: int = 0, verbose: bool = True) -> str:
 
     def compile_one(item):
         src_path, obj = item
-        cmd = [hipcc, *CXXFLAGS, "-c", src_path, "-o", obj]
+        cmd = [hipcc, *CXXFLAGS, *extra, "-c", src_path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src_path}:\n{r.stderr}")
@@ -90,5 +100,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=0)
+    ap.add_argument("--tag", default="", help="build an experiment variant libswiftllm_hip_<tag>.so")
+    ap.add_argument("-D", dest="defines", action="append", default=[], help="macro for the variant, e.g. SWL_PA_DEPTH=4")
     a = ap.parse_args()
-    print(build(force=a.force, jobs=a.jobs))
+    print(build(force=a.force, jobs=a.jobs, tag=a.tag, defines=a.defines))

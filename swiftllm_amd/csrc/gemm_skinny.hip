@@ -478,10 +478,18 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_skinny_ring_kernel(
             acc = mfma32x32x16(a_, b_, acc);                                                         \
         }                                                                                            \
     }
-    // prologue: up to D-1 tiles in flight; x of tile 0 published
+    // prologue: D-1 tiles in flight; x of tile 0 published. UNCONDITIONAL (the host guarantees nkt >= D-1): with
+    // `if (d < nkt)` around these requests the compiler cannot know how many loads are outstanding when it enters the
+    // steady loop and sizes the first wait of every iteration for the fewest — it then waits for the NEXT tile as
+    // well before multiplying the current one (seen in the ISA: vmcnt(7) where vmcnt(17) was due).
+    // ... and in PROGRAM ORDER (scheduling fences): the merge of this block's state with the loop's back edge takes,
+    // per register, the smaller wait count — a prologue whose requests the scheduler has shuffled poisons every
+    // iteration's first wait the same way.
 #pragma unroll
-    for (int d = 0; d < D - 1; ++d)
-        if (d < nkt) SWL_ISSUE(d, d);
+    for (int d = 0; d < D - 1; ++d) {
+        SWL_ISSUE(d, d);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     if constexpr (XNORM) {
         // (after the W loads are on their way) 1/rms of the rows this lane stages, from the producer's per-tile
         // sums of squares, added in tile order; the norm weight of this K-chunk goes to LDS for the whole
@@ -594,6 +602,8 @@ static int choose_k_splits(int N, int K) {
 
 // K-chunks of >= 8 tiles amortise the ring's barriers; shorter ones keep the barrier-free kernel.
 static bool use_ring(int kc) { return kc / kKT >= 8; }
+// The ring kernels request their first RD-1 tiles unconditionally: a K-chunk must hold that many.
+static bool ring_chunk_ok(int kc, int rd) { return kc / kKT >= rd - 1; }
 
 // reduce == false: stop after the partial slabs (a fused consumer sums them: swl_splitk_*)
 template <typename T>
@@ -748,7 +758,7 @@ static int run_fused_partial(const T *x, const T *w, float *slabs, size_t slabs_
     const int kc = K / ks;
     const dim3 grid(N / 128, ks), block(kGemmWaves * 64);
     const int64_t os = N;
-    if (xnorm && kc > kMaxNormK) return SWL_ERR_UNSUPPORTED;
+    if (xnorm && (kc > kMaxNormK || !ring_chunk_ok(kc, kRing))) return SWL_ERR_UNSUPPORTED;
     if (xnorm)
         hipLaunchKernelGGL((gemm_skinny_ring_kernel<T, kGemmPartial, true, EPI>), grid, block, 0, stream, slabs, x,
                            w, M, N, K, kc, xs, os, f);
@@ -797,7 +807,8 @@ extern "C" int swl_gemm_skinny_norm_silu_gate(void *out, const void *x, const fl
     if (M < 0 || I <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
     if (M == 0) return SWL_OK;
     if (!out || !x || !w_up_gate || !ssq_in || !norm_w || ssq_parts <= 0) return SWL_ERR_BAD_ARG;
-    if (M > 32 || (I & 31) || (K & (swl::kKT - 1)) || K > swl::kMaxNormK) return SWL_ERR_UNSUPPORTED;
+    if (M > 32 || (I & 31) || (K & (swl::kKT - 1)) || K > swl::kMaxNormK || !swl::ring_chunk_ok(K, swl::kRing))
+        return SWL_ERR_UNSUPPORTED;
     if (x_row_stride < K || out_row_stride < I || (x_row_stride & 7) || (out_row_stride & 3))
         return SWL_ERR_BAD_ARG;
     if (!swl::aligned16(x) || !swl::aligned16(w_up_gate) || !swl::aligned16(norm_w) ||
@@ -1078,8 +1089,10 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_packed_mt_kernel(
         }                                                                                            \
     }
 #pragma unroll
-    for (int d = 0; d < D - 1; ++d)
-        if (d < nkt) SWL_MT_ISSUE_W(d, d);
+    for (int d = 0; d < D - 1; ++d) {   // unconditional and in program order: see gemm_skinny_ring_kernel (host: nkt >= D-1)
+        SWL_MT_ISSUE_W(d, d);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     SWL_MT_ISSUE_X(0);
     SWL_MT_STAGE_X(0);
     __syncthreads();
@@ -1187,7 +1200,7 @@ template <typename T>
 static int run_gemm_packed_mt(T *out, const T *x, const T *wp, float *ws, size_t ws_bytes, int M, int N, int K,
                               int64_t xs, int64_t os, int ks, hipStream_t stream, bool reduce = true) {
     if (ks <= 0) ks = choose_k_splits_mt(M, N, K);
-    if (K % (kKT * ks) != 0) return SWL_ERR_UNSUPPORTED;
+    if (K % (kKT * ks) != 0 || !ring_chunk_ok(K / ks, kRing)) return SWL_ERR_UNSUPPORTED;
     const dim3 grid((N / 32 + kGemmWaves - 1) / kGemmWaves, ks), block(kGemmWaves * 64);
     const int kc = K / ks;
     if (ks == 1 && reduce) {
@@ -1269,7 +1282,7 @@ extern "C" int swl_gemm_packed_mid_silu_gate(void *out, const void *x, const voi
     if (M < 0 || I <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
     if (M == 0) return SWL_OK;
     if (!out || !x || !w_up_gate_packed) return SWL_ERR_BAD_ARG;
-    if (M > 128 || (I & 31) || (K & (swl::kKT - 1))) return SWL_ERR_UNSUPPORTED;
+    if (M > 128 || (I & 31) || (K & (swl::kKT - 1)) || !swl::ring_chunk_ok(K, swl::kRing)) return SWL_ERR_UNSUPPORTED;
     if (x_row_stride < K || out_row_stride < I || (x_row_stride & 7) || (out_row_stride & 3)) return SWL_ERR_BAD_ARG;
     if (!swl::aligned16(x) || !swl::aligned16(w_up_gate_packed) || (reinterpret_cast<uintptr_t>(out) & 7u))
         return SWL_ERR_BAD_ARG;

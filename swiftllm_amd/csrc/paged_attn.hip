@@ -65,13 +65,15 @@ struct DecodeTile {
     static constexpr int NI = kBlk / TPI;  // load instructions per 16-token block
 };
 
-// One 16-token block for one wave. s/p live only here; m, l, acc persist.
-template <typename T, int D, int G, bool MASKED>
+// One 16-token block for one wave. s/p live only here; m, l, acc persist. `partial` (wave-uniform): the block
+// crosses the end of the sequence and its tail tokens are masked out; the two selects sit behind a uniform branch
+// so the kernel carries ONE copy of this body per ring slot instead of a masked and an unmasked one.
+template <typename T, int D, int G>
 __device__ __forceinline__ void attend_block(const vec8_t<T> (&qv)[G],
                                              const vec8_t<T> (&Kv)[DecodeTile<T, D, G>::NI],
                                              const vec8_t<T> (&Vv)[DecodeTile<T, D, G>::NI],
                                              float (&m)[G], float (&l)[G], float (&acc)[G][8],
-                                             float c, int tok0, int row, int len) {
+                                             float c, int tok0, int row, int len, bool partial) {
     using Tile = DecodeTile<T, D, G>;
     constexpr int NI = Tile::NI;
     float vf[NI][8];
@@ -82,15 +84,17 @@ __device__ __forceinline__ void attend_block(const vec8_t<T> (&qv)[G],
 
     bool valid[NI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) valid[i] = !MASKED || (tok0 + i * Tile::TPI + row < len);
+    for (int i = 0; i < NI; ++i) valid[i] = tok0 + i * Tile::TPI + row < len;
 
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         float s[NI];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            s[i] = group_allreduce_sum<Tile::LPT>(dot8<T>(qv[g], Kv[i], 0.f));
-            if (MASKED && !valid[i]) s[i] = kNegBig;
+        for (int i = 0; i < NI; ++i) s[i] = group_allreduce_sum<Tile::LPT>(dot8<T>(qv[g], Kv[i], 0.f));
+        if (partial) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                if (!valid[i]) s[i] = kNegBig;
         }
         float m_new = m[g];
 #pragma unroll
@@ -101,13 +105,16 @@ __device__ __forceinline__ void attend_block(const vec8_t<T> (&qv)[G],
         // exp2 of that is inf; (m - m_new) is exactly 0.
         const float alpha = fast_exp2((m[g] - m_new) * c);
         float p[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) p[i] = fast_exp2(fmaf(s[i], c, -mc));
+        if (partial) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                if (!valid[i]) p[i] = 0.f;
+        }
         float psum = 0.f;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            p[i] = fast_exp2(fmaf(s[i], c, -mc));
-            if (MASKED && !valid[i]) p[i] = 0.f;
-            psum += p[i];
-        }
+        for (int i = 0; i < NI; ++i) psum += p[i];
         l[g] = fmaf(l[g], alpha, psum);
         m[g] = m_new;
 #pragma unroll
@@ -120,6 +127,20 @@ __device__ __forceinline__ void attend_block(const vec8_t<T> (&qv)[G],
     }
 }
 
+// Ring depth of the K/V register pipeline: a wave keeps kPaDepth 16-token blocks (K + V = 8 KiB, 32 VGPRs each)
+// resident — the one it attends plus kPaDepth-1 in flight. Little's law on this part: one CU needs ~31 GB/s
+// (8 TB/s / 256) against ~2 us of loaded HBM latency = ~64 KB in flight; 8 waves x 1 block in flight (depth 2) is
+// exactly that with nothing to spare, depth 3 doubles it.
+#ifndef SWL_PA_DEPTH
+#define SWL_PA_DEPTH 0      // 0 = by group size (below); an explicit value is for A/B builds
+#endif
+// L2 look-ahead: besides the register ring, a wave touches (one 4-byte load per 128-byte line: lanes 0-31 the K
+// tile, lanes 32-63 the V tile) the block it will load SWL_PA_L2_AHEAD ring rounds later, so the HBM round trip of
+// that block is already under way — bytes in flight per CU stop being bounded by the VGPR file. 0 = off.
+#ifndef SWL_PA_L2_AHEAD
+#define SWL_PA_L2_AHEAD 0
+#endif
+
 // NW = waves per workgroup: 4 for short sequence blocks (latency-bound launches that want many
 // small workgroups), 8 for long ones (one workgroup per CU, every wave streams many KV blocks and the
 // per-workgroup prologue/merge is amortised; 8 waves x 16 KiB of K/V in flight per CU).
@@ -130,7 +151,14 @@ __device__ __forceinline__ void attend_block(const vec8_t<T> (&qv)[G],
 // LDS for its waves, and — in the split that owns the last position — writes the new k/v into the pool and
 // patches them into the registers of the wave that attends that block (the pool read raced with the write).
 template <typename T, int D, int G, int NW, bool QKV = false>
-__global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnParams p) {
+// block_table / seq_lens / seq_ids are passed a second time as __restrict__ kernel arguments: the QKV variant
+// stores into the pools before its main loop, and without the no-alias guarantee the compiler must assume those
+// stores clobber the block table — it then fetches bt[b] with a VECTOR load and waits vmcnt(0) for it, draining
+// the whole K/V ring on every refill (seen in the ISA; the plain variant has no stores and got s_load all along).
+__global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnParams p,
+                                                                    const int *__restrict__ block_table,
+                                                                    const int *__restrict__ seq_lens_r,
+                                                                    const int *__restrict__ seq_ids_r) {
     using Tile = DecodeTile<T, D, G>;
     constexpr int LPT = Tile::LPT, TPI = Tile::TPI, NI = Tile::NI;
     constexpr int NT = NW * 64;
@@ -142,13 +170,13 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
     const int split = blockIdx.x;
     const int kvh = blockIdx.y;
     const int seq = blockIdx.z;
-    const int len = p.seq_lens[seq];
+    const int len = seq_lens_r[seq];
     const int tok_begin = split * p.seq_block_size;
     if (tok_begin >= len) return; // uniform for the workgroup, before any barrier
     const int tok_end = min(len, tok_begin + p.seq_block_size);
     const int blk_end = (tok_end + kBlk - 1) / kBlk;
-    const int seq_id = p.seq_ids[seq];
-    const int *bt = p.block_table + static_cast<int64_t>(seq_id) * p.max_blocks_per_seq;
+    const int seq_id = seq_ids_r[seq];
+    const int *__restrict__ bt = block_table + static_cast<int64_t>(seq_id) * p.max_blocks_per_seq;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -173,51 +201,71 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
     const int last_blk = pos / kBlk;
 
     float m[G], l[G], acc[G][8];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        m[g] = kNegBig;
-        l[g] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
-    }
 
-    vec8_t<T> Ka[NI], Va[NI], Kb[NI], Vb[NI];
-    auto load_block = [&](int b, vec8_t<T>(&Kr)[NI], vec8_t<T>(&Vr)[NI]) {
+    // ring slots: what the 256-VGPR budget of a 2-waves-per-SIMD kernel holds without spilling (accumulators grow
+    // with G): G = 1 -> 4, G = 2 -> 3, G >= 4 -> 2
+    constexpr int ND = SWL_PA_DEPTH > 0 ? (G >= 8 ? 2 : SWL_PA_DEPTH) : (G == 1 ? 4 : (G == 2 ? 3 : 2));
+    vec8_t<T> Kr[ND][NI], Vr[ND][NI];
+    auto load_block = [&](int b, vec8_t<T>(&Kd)[NI], vec8_t<T>(&Vd)[NI]) {
         const int64_t phys = bt[b]; // scalar load: b is wave-uniform
         const int64_t base = (phys * blk_pitch + layer_head) * tile_elems + lane * 8;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            Kr[i] = load8_nt(kc + base + i * 512);
-            Vr[i] = load8_nt(vc + base + i * 512);
+            Kd[i] = load8_nt(kc + base + i * 512);
+            Vd[i] = load8_nt(vc + base + i * 512);
         }
     };
-    auto attend = [&](int b, vec8_t<T>(&Kr)[NI], vec8_t<T>(&Vr)[NI]) {
+    auto attend = [&](int b, vec8_t<T>(&Kd)[NI], vec8_t<T>(&Vd)[NI]) {
         const int tok0 = b * kBlk;
+        attend_block<T, D, G>(qv, Kd, Vd, m, l, acc, c, tok0, row, len, tok0 + kBlk > len);
+    };
+    // Drain steps only (a wave's last block is always attended there): in the QKV variant the block that holds the
+    // token being decoded takes that token's k/v from the prologue's LDS copy — its pool read raced with the store.
+    // Kept out of the steady loop: the per-lane patch costs registers the ring needs.
+    auto attend_tail = [&](int b, vec8_t<T>(&Kd)[NI], vec8_t<T>(&Vd)[NI]) {
         if constexpr (QKV) {
-            if (b == last_blk) { // the new token's slot: take k/v from the prologue, not from the pool
+            const int tok0 = b * kBlk;
+            if (b == last_blk) {
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
                     if (tok0 + i * TPI + row == pos) {
-                        Kr[i] = *reinterpret_cast<const vec8_t<T> *>(&sm_kv[chunk * 8]);
-                        Vr[i] = *reinterpret_cast<const vec8_t<T> *>(&sm_kv[D + chunk * 8]);
+                        Kd[i] = *reinterpret_cast<const vec8_t<T> *>(&sm_kv[chunk * 8]);
+                        Vd[i] = *reinterpret_cast<const vec8_t<T> *>(&sm_kv[D + chunk * 8]);
                     }
             }
         }
-        if (tok0 + kBlk > len)
-            attend_block<T, D, G, true>(qv, Kr, Vr, m, l, acc, c, tok0, row, len);
-        else
-            attend_block<T, D, G, false>(qv, Kr, Vr, m, l, acc, c, tok0, row, len);
+        attend(b, Kd, Vd);
     };
+    // L2 look-ahead for block bb (see SWL_PA_L2_AHEAD). The load is hidden from the compiler's vmcnt bookkeeping
+    // (inline asm): its result is never read; `pf` pins one VGPR for the whole loop so nothing else is allocated
+    // where the in-flight loads land. The compiler's counted waits can only over-wait because of it.
+    int pf = 0;
+    auto touch_block = [&](int bb) {
+        if constexpr (SWL_PA_L2_AHEAD > 0) {
+            if (bb < blk_end) {
+                const int64_t phys = bt[bb];
+                const T *src = (lane < 32 ? kc : vc) + (phys * blk_pitch + layer_head) * tile_elems + (lane & 31) * 64;
+                asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(src) : "memory");
+            }
+        }
+    };
+    // the first ND blocks of this wave go into slots 0..ND-1 (QKV: issued from inside the prologue)
+    auto prefetch_kv = [&](int b0, auto lo_tag, auto hi_tag) {
+#pragma unroll
+        for (int d = decltype(lo_tag)::value; d < decltype(hi_tag)::value; ++d)
+            if (b0 + d * NW < blk_end) load_block(b0 + d * NW, Kr[d], Vr[d]);
+    };
+    constexpr int NDP = ND < 2 ? ND : 2;    // QKV: slots requested while the slab loads of the prologue are pending
 
     int b = tok_begin / kBlk + wave;
     if constexpr (!QKV) {
-        if (b < blk_end) load_block(b, Ka, Va);
+        prefetch_kv(b, IntTag<0>{}, IntTag<ND>{});
     } else {
         // Prologue order matters (loads return in order within a wave): a thread first REQUESTS the slabs of its
         // item, then its wave requests two KV blocks (16 KiB, the stream is running), and only then the item is
         // finished — the slab data never queues behind 16 KiB of KV, and no wave delays its KV requests.
-        const bool owner = tok_end == len; // the split that attends (and stores) the new token
         constexpr int kRot = D / 16;       // rotation items per head
+        const bool owner = tok_end == len; // the split that attends (and stores) the new token
         const int n_items = G * kRot + (owner ? kRot + D / 8 : 0); // <= one per thread
         const int64_t qkv_row = static_cast<int64_t>(p.H + 2 * p.KVH) * D;
         const int64_t slab_stride = static_cast<int64_t>(gridDim.z) * qkv_row;
@@ -229,10 +277,6 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
         const int c = is_rot ? item % kRot : item - (G + 1) * kRot;
         const int head = is_q ? kvh * G + item / kRot : (is_rot ? p.H + kvh : p.H + p.KVH + kvh);
         const int64_t off = row_off + static_cast<int64_t>(head) * D + c * 8;
-        auto prefetch_kv = [&]() {
-            if (b < blk_end) load_block(b, Ka, Va);
-            if (b + NW < blk_end) load_block(b + NW, Kb, Vb);
-        };
         auto finish = [&](vec8_t<T> x0, vec8_t<T> x1, const vec8_t<T> &cv, const vec8_t<T> &sv) {
             if (is_rot) {
                 rotate8<T>(x0, x1, cv, sv);
@@ -274,7 +318,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
                     }
                 }
             }
-            prefetch_kv();
+            prefetch_kv(b, IntTag<0>{}, IntTag<NDP>{});
             if (has) {
                 // slab order, one rounding: the bits of load8_splitk / the stand-alone reduce kernel
                 float4_t sa0 = {0.f, 0.f, 0.f, 0.f}, sb0 = sa0, sa1 = sa0, sb1 = sa0;
@@ -305,7 +349,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
         else if (p.ks == 2) prologue(IntTag<2>{});
         else if (p.ks == 1) prologue(IntTag<1>{});
         else { // many slabs: too many registers to hold them raw — KV first, then the summing loads
-            prefetch_kv();
+            prefetch_kv(b, IntTag<0>{}, IntTag<NDP>{});
             if (has) {
                 vec8_t<T> cv = {}, sv = {}, x1 = {};
                 vec8_t<T> x0 = load8_splitk<T>(p.qkv_slabs, p.ks, slab_stride, off);
@@ -318,24 +362,61 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
                 finish(x0, x1, cv, sv);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);  // do not hoist the next requests above the slab sums (register pressure)
+        prefetch_kv(b, IntTag<NDP>{}, IntTag<ND>{}); // the remaining slots: the slab registers are free again
         __syncthreads();
 #pragma unroll
         for (int g = 0; g < G; ++g) qv[g] = *reinterpret_cast<const vec8_t<T> *>(&sm_q[g * D + chunk * 8]);
     }
-    if (b < blk_end) {
-        bool second_in_flight = QKV;
-        while (true) {
-            if (!second_in_flight && b + NW < blk_end) load_block(b + NW, Kb, Vb);
-            second_in_flight = false;
-            attend(b, Ka, Va);
-            b += NW;
-            if (b >= blk_end) break;
-            if (b + NW < blk_end) load_block(b + NW, Ka, Va);
-            attend(b, Kb, Vb);
-            b += NW;
-            if (b >= blk_end) break;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        m[g] = kNegBig;
+        l[g] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
+    }
+    // steady state: every refill is unconditional, so the waits between slots are exact counted vmcnt waits (a
+    // conditional load in the body makes the compiler wait for one slot more than needed); slot d attends block
+    // b + d*NW and is refilled with block b + (d+ND)*NW
+    constexpr int LA = SWL_PA_L2_AHEAD * ND;    // look-ahead distance in blocks of this wave
+#pragma unroll
+    for (int d = 0; d < LA; ++d) touch_block(b + (ND + d) * NW);
+    if (b + (2 * ND - 1) * NW < blk_end) {
+        // The first ND requests above are conditional (short sequence blocks), so on entry the compiler cannot know how
+        // many loads are outstanding and would size EVERY wait of the loop for the fewest — i.e. wait for the newest
+        // slot before touching the oldest (seen in the ISA of the r01 kernel as well: its prefetch never overlapped
+        // its own compute). One full wait here — all ND slots were requested long ago, this is the pipeline fill —
+        // hands the loop an exact state; from then on every wait in it is a counted vmcnt.
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0), expcnt/lgkmcnt untouched
+      do {
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            // scheduling fences: left alone, the compiler computes all ND blocks back to back behind ONE vmcnt(0)
+            // and sinks every refill to the end of the iteration — nothing in flight while it computes (seen in
+            // the ISA: 34 us instead of 27 at batch 32 x 1k). Pinned, the wait before slot d+1 is a counted one.
+            attend(b + d * NW, Kr[d], Vr[d]);
+            __builtin_amdgcn_sched_barrier(0);
+            load_block(b + (d + ND) * NW, Kr[d], Vr[d]);
+            touch_block(b + (d + ND + LA) * NW);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        b += ND * NW;
+      } while (b + (2 * ND - 1) * NW < blk_end);
+    }
+    // drain: at most 2*ND-1 blocks left, the first ND of them already in their slots
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        if (b + d * NW < blk_end) {
+            attend_tail(b + d * NW, Kr[d], Vr[d]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (b + (d + ND) * NW < blk_end) load_block(b + (d + ND) * NW, Kr[d], Vr[d]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+#pragma unroll
+    for (int d = 0; d < ND - 1; ++d)
+        if (b + (d + ND) * NW < blk_end) attend_tail(b + (d + ND) * NW, Kr[d], Vr[d]);
+    if constexpr (SWL_PA_L2_AHEAD > 0) asm volatile("" ::"v"(pf)); // the pinned register lives to here
 
     // ---- merge the TPI rows of this wave (each row holds tokens == row mod TPI) ----------------
 #pragma unroll
@@ -441,9 +522,11 @@ static int launch_phase1(const PagedAttnParams &p, int Bd, hipStream_t stream) {
     // >= 32 KV blocks per sequence block: 8-wave workgroups (>= 4 blocks per wave); else 4 waves.
     // (G = 8 needs > 256 registers per lane: it stays on 4-wave workgroups, one wave per SIMD.)
     if (G <= 4 && p.seq_block_size >= 32 * kBlk)
-        hipLaunchKernelGGL((paged_attn_phase1_kernel<T, D, G, 8, QKV>), grid, dim3(512), 0, stream, p);
+        hipLaunchKernelGGL((paged_attn_phase1_kernel<T, D, G, 8, QKV>), grid, dim3(512), 0, stream, p, p.block_table,
+                           p.seq_lens, p.seq_ids);
     else
-        hipLaunchKernelGGL((paged_attn_phase1_kernel<T, D, G, 4, QKV>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((paged_attn_phase1_kernel<T, D, G, 4, QKV>), grid, dim3(256), 0, stream, p, p.block_table,
+                           p.seq_lens, p.seq_ids);
     return check_launch();
 }
 

@@ -56,6 +56,74 @@ def init_control_group(timeout_s: int = 600) -> bool:
     return True
 
 
+def _parse_cpulist(text: str) -> List[int]:
+    cpus: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def _gpu_numa_nodes() -> List[int]:
+    """NUMA node of every AMD GPU of this host in device order (KFD topology: GPU nodes carry a non-zero
+    simd_count and their PCI location, from which sysfs gives the node). [] when the host does not tell."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    out = []
+    try:
+        for node in sorted(os.listdir(base), key=int):
+            props = {}
+            with open(os.path.join(base, node, "properties"), encoding="ascii") as f:
+                for line in f:
+                    k, _, v = line.strip().partition(" ")
+                    props[k] = v
+            if int(props.get("simd_count", "0")) == 0:
+                continue        # a CPU node
+            loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+            bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}"
+            with open(f"/sys/bus/pci/devices/{bdf}/numa_node", encoding="ascii") as f:
+                out.append(int(f.read().strip()))
+    except (OSError, ValueError):
+        return []
+    return out
+
+
+def cpus_for_local_rank(local_rank: int, local_world: int, allowed: Sequence[int] = None) -> List[int]:
+    """The host cores replica `local_rank` of `local_world` should run on: the cores of its GPU's NUMA node, split
+    evenly among the replicas that share the node (8 Python processes each feeding one GPU — the
+    host side is the only shared resource of the request-sharded path). Falls back to an even contiguous split of
+    the allowed cores when the topology is not readable."""
+    allowed = sorted(allowed if allowed is not None else os.sched_getaffinity(0))
+    if local_world <= 1 or not allowed:
+        return list(allowed)
+    nodes = _gpu_numa_nodes()
+    if len(nodes) >= local_world and all(n >= 0 for n in nodes[:local_world]):
+        mine = nodes[local_rank]
+        peers = [r for r in range(local_world) if nodes[r] == mine]
+        try:
+            with open(f"/sys/devices/system/node/node{mine}/cpulist", encoding="ascii") as f:
+                node_cpus = [c for c in _parse_cpulist(f.read()) if c in set(allowed)]
+        except OSError:
+            node_cpus = []
+        if len(node_cpus) >= len(peers):
+            b, e = shard_bounds(len(node_cpus), peers.index(local_rank), len(peers))
+            return node_cpus[b:e]
+    b, e = shard_bounds(len(allowed), local_rank, local_world)
+    return allowed[b:e] or list(allowed)
+
+
+def pin_to_local_cores(local_rank: int, local_world: int) -> List[int]:
+    """Apply cpus_for_local_rank to this process (and cap torch's intra-op threads accordingly)."""
+    cpus = cpus_for_local_rank(local_rank, local_world)
+    try:
+        os.sched_setaffinity(0, cpus)
+    except (OSError, AttributeError):
+        return []
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), len(cpus))))
+    return cpus
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()

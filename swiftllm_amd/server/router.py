@@ -44,6 +44,7 @@ def build_app(router: ReplicaRouter):
     import fastapi
     from fastapi.responses import JSONResponse, StreamingResponse
     app = fastapi.FastAPI()
+    no_limit = aiohttp.ClientTimeout(total=None)    # a queued long generation may take longer than aiohttp's 300 s
 
     @app.post("/generate")
     async def generate(req: fastapi.Request):
@@ -54,14 +55,14 @@ def build_app(router: ReplicaRouter):
         if body.get("stream", False):
             async def relay():
                 try:
-                    async with aiohttp.ClientSession() as s, s.post(url, json=body) as r:
+                    async with aiohttp.ClientSession(timeout=no_limit) as s, s.post(url, json=body) as r:
                         async for chunk in r.content.iter_any():
                             yield chunk
                 finally:
                     router.release(i, cost)
             return StreamingResponse(relay(), media_type="text/plain")
         try:
-            async with aiohttp.ClientSession() as s, s.post(url, json=body) as r:
+            async with aiohttp.ClientSession(timeout=no_limit) as s, s.post(url, json=body) as r:
                 return JSONResponse(await r.json(), status_code=r.status)
         finally:
             router.release(i, cost)
@@ -78,8 +79,33 @@ def spawn_replicas(num: int, base_port: int, passthrough: List[str]) -> List[sub
     for i in range(num):
         env = dict(os.environ, HIP_VISIBLE_DEVICES=str(i), HSA_ENABLE_IPC_MODE_LEGACY="0")
         cmd = [sys.executable, "-m", "swiftllm_amd.server.api_server", "--port", str(base_port + 1 + i)] + passthrough
-        procs.append(subprocess.Popen(cmd, env=env))
+        cpus = dp.cpus_for_local_rank(i, num)      # NUMA-local cores of GPU i, disjoint from the other replicas'
+
+        def pin(cpus=cpus):
+            try:
+                os.sched_setaffinity(0, cpus)
+            except OSError:
+                pass
+        procs.append(subprocess.Popen(cmd, env=env, preexec_fn=pin))
     return procs
+
+
+async def wait_until_ready(urls: List[str], timeout_s: float = 1800.0) -> None:
+    """Poll every replica's GET /load until it answers (weights loaded, KV pool profiled)."""
+    import aiohttp
+    deadline = asyncio.get_event_loop().time() + timeout_s
+    async with aiohttp.ClientSession(timeout=aiohttp.ClientTimeout(total=5)) as s:
+        for url in urls:
+            while True:
+                try:
+                    async with s.get(url + "/load") as r:
+                        if r.status == 200:
+                            break
+                except (aiohttp.ClientError, asyncio.TimeoutError):
+                    pass
+                if asyncio.get_event_loop().time() > deadline:
+                    raise RuntimeError(f"replica {url} did not come up within {timeout_s:.0f} s")
+                await asyncio.sleep(0.5)
 
 
 def main():
@@ -92,6 +118,7 @@ def main():
     router = ReplicaRouter([f"http://127.0.0.1:{args.port + 1 + i}" for i in range(args.num_replicas)])
     try:
         import uvicorn
+        asyncio.run(wait_until_ready(router.urls))      # accept traffic only when every replica can serve it
         uvicorn.run(build_app(router), host=args.host, port=args.port, log_level="warning")
     finally:
         for p in procs:

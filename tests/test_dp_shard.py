@@ -70,3 +70,18 @@ def test_two_rank_gloo_control_group():
     assert u0 == u1 == 70.0         # whole-job units = sum over ranks
     assert s0 == s1 == 2.0          # whole-job time = the slowest rank
     assert e0 == e1 == [[0, 1, 2, 3], [4, 5, 6]]
+
+
+def test_replica_core_sets_are_disjoint_and_cover_the_allowed_cores():
+    """Per-replica CPU pinning: whatever the host topology says, the N replicas of a node get
+    disjoint, non-empty core sets drawn from the allowed cores."""
+    from swiftllm_amd import dp as _dp
+    allowed = list(range(3, 67))
+    for world in (1, 2, 4, 8):
+        sets = [_dp.cpus_for_local_rank(r, world, allowed) for r in range(world)]
+        assert all(s for s in sets)
+        flat = [c for s in sets for c in s]
+        assert set(flat) <= set(allowed)
+        if world > 1:
+            assert len(flat) == len(set(flat))
+    assert _dp._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]

@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--dtype", default="bfloat16")
     ap.add_argument("--iters", type=int, default=256)
     ap.add_argument("--sbs", type=int, default=0, help="override the split-K width")
+    ap.add_argument("--qkv", type=int, default=0, help="k-splits of fused-qkv slabs: time swl_paged_attn_decode_qkv "
+                                                       "(rotary + KV store in the prologue), the variant a decode step runs")
     a = ap.parse_args()
     H, KVH, D, B, n, L = SHAPES[a.shape]
     dtype = getattr(torch, a.dtype)
@@ -61,13 +63,24 @@ def main():
     ec = types.SimpleNamespace(block_size=16)
     q = torch.randn(B, H, D, device=dev).to(dtype)
     o = torch.empty_like(q)
+    if a.qkv:
+        from swiftllm_amd.worker.kernels.linear import SplitKPartials
+        from swiftllm_amd.worker.kernels.paged_attn import paged_attention_from_qkv_splitk
+        st.position_indices = (st.decoding_seq_lens - 1).contiguous()
+        ang = torch.rand(n + 8, D // 2, device=dev) * 6.28
+        st.position_cos, st.position_sin = torch.cos(ang).to(dtype), torch.sin(ang).to(dtype)
+        slabs = torch.randn(a.qkv, B, (H + 2 * KVH) * D, device=dev, dtype=torch.float32) * 0.5
+        slab_part = SplitKPartials(slabs, a.qkv, B, (H + 2 * KVH) * D, dtype)
+        run = lambda layer: paged_attention_from_qkv_splitk(slab_part, kc, vc, bt, mc, ec, st, layer, o)   # noqa: E731
+    else:
+        run = lambda layer: K.paged_attention(q, kc, vc, bt, mc, ec, st, layer, o)   # noqa: E731
     for i in range(min(a.iters, 2 * L)):
-        K.paged_attention(q, kc, vc, bt, mc, ec, st, i % L, o)
+        run(i % L)
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     start.record()
     for i in range(a.iters):
-        K.paged_attention(q, kc, vc, bt, mc, ec, st, i % L, o)
+        run(i % L)
     stop.record()
     stop.synchronize()
     us = start.elapsed_time(stop) * 1e3 / a.iters
@@ -75,7 +88,7 @@ def main():
     kv = sum(lens) * 2 * KVH * D * e
     part = B * H * nsb * (D + 1) * 4 * 2 if nsb > 1 else 0
     alg = kv + 2 * B * H * D * e + part
-    print(json.dumps(dict(shape=a.shape, dtype=a.dtype, H=H, KVH=KVH, D=D, batch=B, len=n, seq_block_size=sbs,
+    print(json.dumps(dict(shape=a.shape, qkv_slabs=a.qkv, lib=os.environ.get("SWIFTLLM_HIP_LIB", "default"), dtype=a.dtype, H=H, KVH=KVH, D=D, batch=B, len=n, seq_block_size=sbs,
                           num_seq_blocks=nsb, workgroups=B * KVH * nsb, us_per_op=round(us, 2),
                           alg_bytes=alg, kv_bytes=kv, GBps=round(alg / us / 1e3, 1),
                           frac_of_8TBps=round(alg / us / 1e3 / 8000, 4), iters=a.iters)))

@@ -334,6 +334,33 @@ int swl_splitk_rotary_store_kv_decode(void *q_out, void *k_out, void *v_out, con
 int swl_decode_positions(int32_t *pos_idx, const int32_t *seq_lens, int32_t num_decoding_seqs,
                          swl_stream_t stream);
 
+/* ---- deferred RMSNorm on the decode fast path ---------------------------------------------------------------------
+ * fused_add_rmsnorm (reference rmsnorm.py:67-89, called at transformer_layer.py:46,120) needs a whole token row before it
+ * can write anything, so as a split-K consumer it runs one workgroup per token (32 workgroups on 256 CUs). The 1/rms is
+ * a per-row scalar that commutes with the projection that follows, so the element-wise part runs fully parallel here and
+ * the consumers below apply the scale in fp32 before their one rounding:
+ *   swl_splitk_add_scale: residual[t, :] += round(sum_k slabs[k][t, :]) (stored, rounded to the storage dtype, as the
+ *     reference stores it); x_scaled = round(residual * w); ssq_out[hidden / 1024][num_tokens] = per-1024-column sums of
+ *     squares of the updated residual rows. hidden % 1024 == 0.
+ *   swl_gemm_skinny_packed_silu_gate_rs: swl_gemm_skinny_packed_silu_gate of rstd[m] * (x_scaled . [up ; gate]^T),
+ *     rstd[m] = 1/sqrt(sum_p row_ssq[p][m] / K + eps). Replaces transformer_layer.py:120-127 for decode batches.
+ *   swl_paged_attn_decode_qkv_rs: swl_paged_attn_decode_qkv whose fused-qkv slab sums are scaled the same way before they
+ *     are rounded, rotated and stored (transformer_layer.py:46-77 + paged_attn.py:152-222). k_splits in {1, 2, 4}.
+ * ssq_parts <= 8 everywhere. */
+int swl_splitk_add_scale(void *x_scaled, void *residual, const void *w, const float *slabs, int32_t k_splits,
+                         float *ssq_out, int64_t num_tokens, int32_t hidden, int32_t dtype, swl_stream_t stream);
+int swl_gemm_skinny_packed_silu_gate_rs(void *out, const void *x, const void *w_up_gate_packed, const float *row_ssq,
+                                        int32_t ssq_parts, float eps, int32_t M, int32_t I, int32_t K,
+                                        int64_t x_row_stride, int64_t out_row_stride, int32_t dtype, swl_stream_t stream);
+int swl_paged_attn_decode_qkv_rs(void *o, const float *qkv_slabs, int32_t k_splits, const float *row_ssq,
+                                 int32_t ssq_parts, int32_t hidden, float eps, const void *cos_table,
+                                 const void *sin_table, const int32_t *pos_idx, void *k_cache, void *v_cache,
+                                 const int32_t *block_table, const int32_t *seq_ids, const int32_t *seq_lens,
+                                 void *scratch, float softmax_scale, int32_t num_decoding_seqs, int32_t num_q_heads,
+                                 int32_t num_kv_heads, int32_t head_dim, int32_t num_layers, int32_t block_size,
+                                 int32_t cur_layer, int32_t max_blocks_per_seq, int32_t seq_block_size,
+                                 int32_t num_seq_blocks, int64_t o_tok_stride, int32_t dtype, swl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

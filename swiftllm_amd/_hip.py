@@ -72,6 +72,10 @@ SIGNATURES = {
                                        _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32,
                                        _I64, _I64, _I32, _P],
     "swl_splitk_fused_add_rmsnorm": [_P, _P, _P, _F32, _P, _I32, _I64, _I32, _I32, _P],
+    "swl_splitk_add_scale": [_P, _P, _P, _P, _I32, _P, _I64, _I32, _I32, _P],
+    "swl_gemm_skinny_packed_silu_gate_rs": [_P, _P, _P, _P, _I32, _F32, _I32, _I32, _I32, _I64, _I64, _I32, _P],
+    "swl_paged_attn_decode_qkv_rs": [_P, _P, _I32, _P, _I32, _I32, _F32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F32, _I32,
+                                     _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I32, _P],
     "swl_splitk_rotary_store_kv_decode": [_P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32,
                                           _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _P],
 }

@@ -49,7 +49,7 @@ def _newer(target: str, deps) -> bool:
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force: bool = False, jobs: int = 0, verbose: bool = True, tag: str = "", defines=()) -> str:
+def build(force: bool = False, jobs: int = 0, verbose: bool = True, tag: str = "", defines=(), swap=None) -> str:
     """Build the library. `tag` + `defines` (-D macros) build an EXPERIMENT variant next to it
     (libswiftllm_hip_<tag>.so, objects under build/<tag>/): tools/ select one with SWIFTLLM_HIP_LIB to A/B a
     kernel parameter on the GPU box without touching the product library."""
@@ -57,16 +57,18 @@ def build(force: bool = False, jobs: int = 0, verbose: bool = True, tag: str = "
     global OBJ_DIR, LIB
     obj_dir = os.path.join(HERE, "build", tag) if tag else OBJ_DIR
     lib = os.path.join(HERE, f"libswiftllm_hip_{tag}.so") if tag else LIB
-    return _build(hipcc, obj_dir, lib, [f"-D{d}" for d in defines], force, jobs, verbose)
+    return _build(hipcc, obj_dir, lib, [f"-D{d}" for d in defines], force, jobs, verbose, swap or {})
 
 
-def _build(hipcc, OBJ_DIR, LIB, extra, force, jobs, verbose) -> str:
+def _build(hipcc, OBJ_DIR, LIB, extra, force, jobs, verbose, swap) -> str:
+    """`swap`: {source name: replacement path} — an experiment variant may compile another file in a source's place
+    (e.g. an older revision of one kernel for an A/B run)."""
     os.makedirs(OBJ_DIR, exist_ok=True)
     hdrs = [h if os.path.isabs(h) else os.path.join(HERE, h) for h in HEADERS]
     hdrs.append(os.path.abspath(__file__))
     todo, objs = [], []
     for src in SOURCES:
-        src_path = os.path.join(HERE, src)
+        src_path = swap.get(src, os.path.join(HERE, src))
         obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         objs.append(obj)
         if force or not _newer(obj, [src_path] + hdrs):
@@ -74,7 +76,7 @@ def _build(hipcc, OBJ_DIR, LIB, extra, force, jobs, verbose) -> str:
 
     def compile_one(item):
         src_path, obj = item
-        cmd = [hipcc, *CXXFLAGS, *extra, "-c", src_path, "-o", obj]
+        cmd = [hipcc, *CXXFLAGS, *extra, f"-I{HERE}", "-c", src_path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src_path}:\n{r.stderr}")
@@ -102,5 +104,6 @@ if __name__ == "__main__":
     ap.add_argument("--jobs", type=int, default=0)
     ap.add_argument("--tag", default="", help="build an experiment variant libswiftllm_hip_<tag>.so")
     ap.add_argument("-D", dest="defines", action="append", default=[], help="macro for the variant, e.g. SWL_PA_DEPTH=4")
+    ap.add_argument("--swap", action="append", default=[], metavar="NAME=PATH", help="compile PATH in place of source NAME")
     a = ap.parse_args()
-    print(build(force=a.force, jobs=a.jobs, tag=a.tag, defines=a.defines))
+    print(build(force=a.force, jobs=a.jobs, tag=a.tag, defines=a.defines, swap=dict(x.split("=", 1) for x in a.swap)))

@@ -235,10 +235,13 @@ __device__ __forceinline__ void splitk_finish(const GemmFuse &f, const float *sl
 
 // acc[r] = out^T[n = n0 + (r&3) + 8*(r>>2) + 4*hf][m = l32] -> the three output modes.
 // `wtiles + w * wave_pitch` is wave w's private W tile (reused as exchange space in SiLU-gate mode).
+// `rs`: deferred-RMSNorm row scale of token m = lane % 32 (rmsnorm.hip: splitk_add_scale_kernel), applied in fp32
+// before the projection's one rounding; 1.0f (exact no-op) everywhere else.
 template <typename T, int MODE, bool COHERENT = false>
 __device__ __forceinline__ void gemm_epilogue(const float16_t &acc, void *__restrict__ out_, T *wtiles,
                                               int wave_pitch, int wave, int lane, bool is_gate, bool tile_ok,
-                                              int col0, int n0, int ksplit, int M, int N, int64_t out_stride) {
+                                              int col0, int n0, int ksplit, int M, int N, int64_t out_stride,
+                                              float rs = 1.0f) {
     const int l32 = lane & 31;
     const int hf = lane >> 5;
     if constexpr (MODE == kGemmSiluGate) {
@@ -248,7 +251,7 @@ __device__ __forceinline__ void gemm_epilogue(const float16_t &acc, void *__rest
         if (is_gate) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float g = to_f(to_t<T>(acc[r]));
+                const float g = to_f(to_t<T>(acc[r] * rs));
                 mine[l32 * 40 + (r & 3) + 8 * (r >> 2) + 4 * hf] = to_t<T>(g / (1.0f + expf(-g)));
             }
         }
@@ -262,7 +265,7 @@ __device__ __forceinline__ void gemm_epilogue(const float16_t &acc, void *__rest
                 const vec4 a = *reinterpret_cast<const vec4 *>(act + l32 * 40 + 8 * r4 + 4 * hf);
                 vec4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = mul_t<T>(to_t<T>(acc[4 * r4 + e]), a[e]);
+                for (int e = 0; e < 4; ++e) v[e] = mul_t<T>(to_t<T>(acc[4 * r4 + e] * rs), a[e]);
                 *reinterpret_cast<vec4 *>(o + 8 * r4) = v;
             }
         }
@@ -440,6 +443,16 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_skinny_ring_kernel(
 
     float rstd[XL];
 
+    // deferred RMSNorm (SiLU-gate mode, packed W): the per-1024-column sums of squares of this lane's token row, requested
+    // BEFORE the weight stream (oldest loads: no wait of the pipeline ever includes them) and summed after the K loop
+    float ssv[8];
+    const bool row_scaled = !XNORM && EPI == kEpiNone && fuse.ssq_in != nullptr;
+    if (row_scaled) {
+        const int m = min(lane & 31, M - 1);
+#pragma unroll
+        for (int p2 = 0; p2 < 8; ++p2) ssv[p2] = p2 < fuse.ssq_parts ? fuse.ssq_in[p2 * M + m] : 0.f;
+    }
+
     vec8_t<T> wr[D][8], xr[D][XL];
     float16_t acc = float16_t{};
     // x loads go first: they are the ones the stage-ahead below waits for (loads return in order)
@@ -478,18 +491,12 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_skinny_ring_kernel(
             acc = mfma32x32x16(a_, b_, acc);                                                         \
         }                                                                                            \
     }
-    // prologue: D-1 tiles in flight; x of tile 0 published. UNCONDITIONAL (the host guarantees nkt >= D-1): with
-    // `if (d < nkt)` around these requests the compiler cannot know how many loads are outstanding when it enters the
-    // steady loop and sizes the first wait of every iteration for the fewest — it then waits for the NEXT tile as
-    // well before multiplying the current one (seen in the ISA: vmcnt(7) where vmcnt(17) was due).
-    // ... and in PROGRAM ORDER (scheduling fences): the merge of this block's state with the loop's back edge takes,
-    // per register, the smaller wait count — a prologue whose requests the scheduler has shuffled poisons every
-    // iteration's first wait the same way.
+    // prologue: up to D-1 tiles in flight; x of tile 0 published. (Tried in r02: unconditional requests in program
+    // order, so that the first wait of every iteration is sized exactly instead of conservatively — vmcnt(17) instead
+    // of vmcnt(7) in the ISA. No measurable difference on MI355X: 39.7 us either way for the up/gate projection.)
 #pragma unroll
-    for (int d = 0; d < D - 1; ++d) {
-        SWL_ISSUE(d, d);
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int d = 0; d < D - 1; ++d)
+        if (d < nkt) SWL_ISSUE(d, d);
     if constexpr (XNORM) {
         // (after the W loads are on their way) 1/rms of the rows this lane stages, from the producer's per-tile
         // sums of squares, added in tile order; the norm weight of this K-chunk goes to LDS for the whole
@@ -554,8 +561,13 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_skinny_ring_kernel(
         // no W tiles in LDS: the SiLU-gate exchange (32 x 40 elements per wave) reuses the x buffers once every
         // wave is done reading them
         if constexpr (MODE == kGemmSiluGate) __syncthreads();
+        float rs = 1.0f;
+        if (row_scaled) {
+            const float ss = ((ssv[0] + ssv[1]) + (ssv[2] + ssv[3])) + ((ssv[4] + ssv[5]) + (ssv[6] + ssv[7]));
+            rs = 1.0f / sqrtf(ss / static_cast<float>(K) + fuse.eps); // rmsnorm.hip's formula
+        }
         gemm_epilogue<T, MODE, false>(acc, out_, &lds[0][0], 32 * 40, wave, lane, is_gate, tile_ok, col0, n0, ksplit,
-                                      M, N, out_stride);
+                                      M, N, out_stride, rs);
     } else {
         gemm_epilogue<T, MODE, EPI != kEpiNone>(acc, out_, &lds[PACKED ? 0 : 2][0], 32 * kKT, wave, lane, is_gate,
                                                 tile_ok, col0, n0, ksplit, M, N, out_stride);
@@ -602,8 +614,6 @@ static int choose_k_splits(int N, int K) {
 
 // K-chunks of >= 8 tiles amortise the ring's barriers; shorter ones keep the barrier-free kernel.
 static bool use_ring(int kc) { return kc / kKT >= 8; }
-// The ring kernels request their first RD-1 tiles unconditionally: a K-chunk must hold that many.
-static bool ring_chunk_ok(int kc, int rd) { return kc / kKT >= rd - 1; }
 
 // reduce == false: stop after the partial slabs (a fused consumer sums them: swl_splitk_*)
 template <typename T>
@@ -758,7 +768,7 @@ static int run_fused_partial(const T *x, const T *w, float *slabs, size_t slabs_
     const int kc = K / ks;
     const dim3 grid(N / 128, ks), block(kGemmWaves * 64);
     const int64_t os = N;
-    if (xnorm && (kc > kMaxNormK || !ring_chunk_ok(kc, kRing))) return SWL_ERR_UNSUPPORTED;
+    if (xnorm && kc > kMaxNormK) return SWL_ERR_UNSUPPORTED;
     if (xnorm)
         hipLaunchKernelGGL((gemm_skinny_ring_kernel<T, kGemmPartial, true, EPI>), grid, block, 0, stream, slabs, x,
                            w, M, N, K, kc, xs, os, f);
@@ -807,8 +817,7 @@ extern "C" int swl_gemm_skinny_norm_silu_gate(void *out, const void *x, const fl
     if (M < 0 || I <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
     if (M == 0) return SWL_OK;
     if (!out || !x || !w_up_gate || !ssq_in || !norm_w || ssq_parts <= 0) return SWL_ERR_BAD_ARG;
-    if (M > 32 || (I & 31) || (K & (swl::kKT - 1)) || K > swl::kMaxNormK || !swl::ring_chunk_ok(K, swl::kRing))
-        return SWL_ERR_UNSUPPORTED;
+    if (M > 32 || (I & 31) || (K & (swl::kKT - 1)) || K > swl::kMaxNormK) return SWL_ERR_UNSUPPORTED;
     if (x_row_stride < K || out_row_stride < I || (x_row_stride & 7) || (out_row_stride & 3))
         return SWL_ERR_BAD_ARG;
     if (!swl::aligned16(x) || !swl::aligned16(w_up_gate) || !swl::aligned16(norm_w) ||
@@ -909,13 +918,13 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(T *__restrict__ dst, c
 
 template <typename T, int MODE>
 static void launch_packed(dim3 grid, hipStream_t stream, void *out, const T *x, const T *wp, int M, int N, int K, int kc,
-                          int64_t xs, int64_t os) {
+                          int64_t xs, int64_t os, const GemmFuse &fuse = GemmFuse{}) {
     if (use_ring(kc))
         hipLaunchKernelGGL((gemm_skinny_ring_kernel<T, MODE, false, kEpiNone, true, 3>), grid, dim3(kGemmWaves * 64), 0,
-                           stream, out, x, wp, M, N, K, kc, xs, os, GemmFuse{});
+                           stream, out, x, wp, M, N, K, kc, xs, os, fuse);
     else
         hipLaunchKernelGGL((gemm_skinny_ring_kernel<T, MODE, false, kEpiNone, true, 2>), grid, dim3(kGemmWaves * 64), 0,
-                           stream, out, x, wp, M, N, K, kc, xs, os, GemmFuse{});
+                           stream, out, x, wp, M, N, K, kc, xs, os, fuse);
 }
 
 template <typename T>
@@ -1015,6 +1024,35 @@ extern "C" int swl_gemm_skinny_packed_silu_gate(void *out, const void *x, const 
     return swl::check_launch();
 }
 
+/* swl_gemm_skinny_packed_silu_gate on an input whose RMSNorm scale is still pending (deferred normalisation,
+ * swl_splitk_add_scale): x = round(residual * w_norm), row_ssq[ssq_parts][M] the per-1024-column sums of squares of the
+ * residual rows; out[m, :] = up * silu(gate) of rstd[m] * (x . [up ; gate]^T), rstd = 1/sqrt(sum_p row_ssq[p][m] / K + eps),
+ * the scale applied in fp32 before the projection's rounding. ssq_parts <= 8. Replaces fused_add_rmsnorm + linear +
+ * silu_and_mul of transformer_layer.py:120-127 on the decode fast path. */
+extern "C" int swl_gemm_skinny_packed_silu_gate_rs(void *out, const void *x, const void *w_up_gate_packed,
+                                                   const float *row_ssq, int32_t ssq_parts, float eps, int32_t M,
+                                                   int32_t I, int32_t K, int64_t x_row_stride, int64_t out_row_stride,
+                                                   int32_t dtype, swl_stream_t stream) {
+    if (M < 0 || I <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
+    if (M == 0) return SWL_OK;
+    if (!out || !x || !w_up_gate_packed || !row_ssq || ssq_parts <= 0) return SWL_ERR_BAD_ARG;
+    if (M > 32 || (I & 31) || (K & (swl::kKT - 1)) || ssq_parts > 8) return SWL_ERR_UNSUPPORTED;
+    if (x_row_stride < K || out_row_stride < I || (x_row_stride & 7) || (out_row_stride & 3)) return SWL_ERR_BAD_ARG;
+    if (!swl::aligned16(x) || !swl::aligned16(w_up_gate_packed) || (reinterpret_cast<uintptr_t>(out) & 7u))
+        return SWL_ERR_BAD_ARG;
+    swl::GemmFuse f{};
+    f.ssq_in = row_ssq;
+    f.ssq_parts = ssq_parts;
+    f.eps = eps;
+    const dim3 grid((I / 32 + 1) / 2, 1);
+    SWL_DISPATCH_DTYPE(dtype, T, {
+        swl::launch_packed<T, swl::kGemmSiluGate>(grid, static_cast<hipStream_t>(stream), out, static_cast<const T *>(x),
+                                                  static_cast<const T *>(w_up_gate_packed), M, I, K, K, x_row_stride,
+                                                  out_row_stride, f);
+    });
+    return swl::check_launch();
+}
+
 // ---- medium batches on packed weights: 32 < M <= 128 -----------------------------------------------------------
 // With W arriving in fragment order there is no LDS traffic for W at all, so MT = 2 or 4 blocks of 32 tokens can
 // share every W fragment at the price of MT x-fragment reads per k-step (1 LDS read per MFMA; the row-major attempt
@@ -1089,10 +1127,8 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_packed_mt_kernel(
         }                                                                                            \
     }
 #pragma unroll
-    for (int d = 0; d < D - 1; ++d) {   // unconditional and in program order: see gemm_skinny_ring_kernel (host: nkt >= D-1)
-        SWL_MT_ISSUE_W(d, d);
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int d = 0; d < D - 1; ++d)
+        if (d < nkt) SWL_MT_ISSUE_W(d, d);
     SWL_MT_ISSUE_X(0);
     SWL_MT_STAGE_X(0);
     __syncthreads();
@@ -1200,7 +1236,7 @@ template <typename T>
 static int run_gemm_packed_mt(T *out, const T *x, const T *wp, float *ws, size_t ws_bytes, int M, int N, int K,
                               int64_t xs, int64_t os, int ks, hipStream_t stream, bool reduce = true) {
     if (ks <= 0) ks = choose_k_splits_mt(M, N, K);
-    if (K % (kKT * ks) != 0 || !ring_chunk_ok(K / ks, kRing)) return SWL_ERR_UNSUPPORTED;
+    if (K % (kKT * ks) != 0) return SWL_ERR_UNSUPPORTED;
     const dim3 grid((N / 32 + kGemmWaves - 1) / kGemmWaves, ks), block(kGemmWaves * 64);
     const int kc = K / ks;
     if (ks == 1 && reduce) {
@@ -1282,7 +1318,7 @@ extern "C" int swl_gemm_packed_mid_silu_gate(void *out, const void *x, const voi
     if (M < 0 || I <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
     if (M == 0) return SWL_OK;
     if (!out || !x || !w_up_gate_packed) return SWL_ERR_BAD_ARG;
-    if (M > 128 || (I & 31) || (K & (swl::kKT - 1)) || !swl::ring_chunk_ok(K, swl::kRing)) return SWL_ERR_UNSUPPORTED;
+    if (M > 128 || (I & 31) || (K & (swl::kKT - 1))) return SWL_ERR_UNSUPPORTED;
     if (x_row_stride < K || out_row_stride < I || (x_row_stride & 7) || (out_row_stride & 3)) return SWL_ERR_BAD_ARG;
     if (!swl::aligned16(x) || !swl::aligned16(w_up_gate_packed) || (reinterpret_cast<uintptr_t>(out) & 7u))
         return SWL_ERR_BAD_ARG;

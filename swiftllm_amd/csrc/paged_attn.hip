@@ -56,6 +56,11 @@ struct PagedAttnParams {
     int ks;
     const void *cos_t, *sin_t; // rope tables [positions][D/2]
     const int *pos_idx;        // table row per sequence (NULL: seq_len - 1)
+    // deferred RMSNorm (rmsnorm.hip, splitk_add_scale_kernel): the qkv projection ran on un-normalised activations;
+    // its fp32 slab sums are multiplied by rstd[seq] = 1/sqrt(sum_p row_ssq[p][seq] / hidden + eps) before their rounding
+    const float *row_ssq; // [ssq_parts][Bd], NULL = the slabs are final
+    int ssq_parts, hidden;
+    float eps;
 };
 
 template <typename T, int D, int G>
@@ -206,14 +211,16 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
     // with G): G = 1 -> 4, G = 2 -> 3, G >= 4 -> 2
     constexpr int ND = SWL_PA_DEPTH > 0 ? (G >= 8 ? 2 : SWL_PA_DEPTH) : (G == 1 ? 4 : (G == 2 ? 3 : 2));
     vec8_t<T> Kr[ND][NI], Vr[ND][NI];
-    auto load_block = [&](int b, vec8_t<T>(&Kd)[NI], vec8_t<T>(&Vd)[NI]) {
-        const int64_t phys = bt[b]; // scalar load: b is wave-uniform
+    auto load_phys = [&](int64_t phys, vec8_t<T>(&Kd)[NI], vec8_t<T>(&Vd)[NI]) {
         const int64_t base = (phys * blk_pitch + layer_head) * tile_elems + lane * 8;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             Kd[i] = load8_nt(kc + base + i * 512);
             Vd[i] = load8_nt(vc + base + i * 512);
         }
+    };
+    auto load_block = [&](int b, vec8_t<T>(&Kd)[NI], vec8_t<T>(&Vd)[NI]) {
+        load_phys(bt[b], Kd, Vd); // scalar load: b is wave-uniform
     };
     auto attend = [&](int b, vec8_t<T>(&Kd)[NI], vec8_t<T>(&Vd)[NI]) {
         const int tok0 = b * kBlk;
@@ -300,6 +307,13 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
             constexpr int KS = decltype(ks_tag)::value;
             float4_t a0[KS], b0[KS], a1[KS], b1[KS];
             vec8_t<T> cv = {}, sv = {};
+            float ssv[8];
+            const bool row_scaled = p.row_ssq != nullptr; // (uniform; same memory round trip as the slabs)
+            if (row_scaled) {
+#pragma unroll
+                for (int q2 = 0; q2 < 8; ++q2)
+                    ssv[q2] = q2 < p.ssq_parts ? p.row_ssq[q2 * static_cast<int>(gridDim.z) + seq] : 0.f;
+            }
             if (has) {
                 const float *s0 = p.qkv_slabs + off;
 #pragma unroll
@@ -334,13 +348,18 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
                         sb1 += b1[k];
                     }
                 }
+                float rs = 1.0f; // (x * 1.0f is exact: one code path)
+                if (row_scaled) {
+                    const float ss = ((ssv[0] + ssv[1]) + (ssv[2] + ssv[3])) + ((ssv[4] + ssv[5]) + (ssv[6] + ssv[7]));
+                    rs = 1.0f / sqrtf(ss / static_cast<float>(p.hidden) + p.eps);
+                }
                 vec8_t<T> x0, x1;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    x0[e] = static_cast<T>(sa0[e]);
-                    x0[4 + e] = static_cast<T>(sb0[e]);
-                    x1[e] = static_cast<T>(sa1[e]);
-                    x1[4 + e] = static_cast<T>(sb1[e]);
+                    x0[e] = static_cast<T>(sa0[e] * rs);
+                    x0[4 + e] = static_cast<T>(sb0[e] * rs);
+                    x1[e] = static_cast<T>(sa1[e] * rs);
+                    x1[4 + e] = static_cast<T>(sb1[e] * rs);
                 }
                 finish(x0, x1, cv, sv);
             }
@@ -394,9 +413,13 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
             // scheduling fences: left alone, the compiler computes all ND blocks back to back behind ONE vmcnt(0)
             // and sinks every refill to the end of the iteration — nothing in flight while it computes (seen in
             // the ISA: 34 us instead of 27 at batch 32 x 1k). Pinned, the wait before slot d+1 is a counted one.
+            // (the block-table entry of the refill is requested BEFORE the block is attended: behind the fence its
+            // scalar-load round trip would sit between every attend and the refill it feeds)
+            const int64_t phys_next = bt[b + (d + ND) * NW];
+            __builtin_amdgcn_sched_barrier(0);
             attend(b + d * NW, Kr[d], Vr[d]);
             __builtin_amdgcn_sched_barrier(0);
-            load_block(b + (d + ND) * NW, Kr[d], Vr[d]);
+            load_phys(phys_next, Kr[d], Vr[d]);
             touch_block(b + (d + ND + LA) * NW);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -679,6 +702,16 @@ extern "C" int swl_paged_attn_decode(void *o, const void *q, const void *k_cache
 
 /* Decode attention fed by the split-K slabs of the fused qkv projection: rotary + KV-store of the new token run
  * in the attention kernel's prologue (no launch of their own), the new k/v are attended from registers. */
+static int paged_attn_decode_qkv_impl(void *o, const float *qkv_slabs, int32_t k_splits, const void *cos_table,
+                                      const void *sin_table, const int32_t *pos_idx, void *k_cache, void *v_cache,
+                                      const int32_t *block_table, const int32_t *seq_ids, const int32_t *seq_lens,
+                                      void *scratch, float softmax_scale, int32_t num_decoding_seqs,
+                                      int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, int32_t num_layers,
+                                      int32_t block_size, int32_t cur_layer, int32_t max_blocks_per_seq,
+                                      int32_t seq_block_size, int32_t num_seq_blocks, int64_t o_tok_stride, int32_t dtype,
+                                      swl_stream_t stream, const float *row_ssq, int32_t ssq_parts, int32_t hidden,
+                                      float eps);
+
 extern "C" int swl_paged_attn_decode_qkv(void *o, const float *qkv_slabs, int32_t k_splits, const void *cos_table,
                                          const void *sin_table, const int32_t *pos_idx, void *k_cache,
                                          void *v_cache, const int32_t *block_table, const int32_t *seq_ids,
@@ -688,6 +721,46 @@ extern "C" int swl_paged_attn_decode_qkv(void *o, const float *qkv_slabs, int32_
                                          int32_t cur_layer, int32_t max_blocks_per_seq, int32_t seq_block_size,
                                          int32_t num_seq_blocks, int64_t o_tok_stride, int32_t dtype,
                                          swl_stream_t stream) {
+    return paged_attn_decode_qkv_impl(o, qkv_slabs, k_splits, cos_table, sin_table, pos_idx, k_cache, v_cache, block_table,
+                                      seq_ids, seq_lens, scratch, softmax_scale, num_decoding_seqs, num_q_heads,
+                                      num_kv_heads, head_dim, num_layers, block_size, cur_layer, max_blocks_per_seq,
+                                      seq_block_size, num_seq_blocks, o_tok_stride, dtype, stream, nullptr, 0, 0, 0.f);
+}
+
+/* swl_paged_attn_decode_qkv on the slabs of a qkv projection whose input had its RMSNorm scale deferred
+ * (swl_splitk_add_scale): row_ssq[ssq_parts][num_decoding_seqs] are the per-1024-column sums of squares of the residual
+ * rows, `hidden` their length; the slab sums are multiplied by 1/sqrt(sum/hidden + eps) in fp32 before they are rounded,
+ * rotated and stored. k_splits in {1, 2, 4}, ssq_parts <= 8. */
+extern "C" int swl_paged_attn_decode_qkv_rs(void *o, const float *qkv_slabs, int32_t k_splits, const float *row_ssq,
+                                            int32_t ssq_parts, int32_t hidden, float eps, const void *cos_table,
+                                            const void *sin_table, const int32_t *pos_idx, void *k_cache,
+                                            void *v_cache, const int32_t *block_table, const int32_t *seq_ids,
+                                            const int32_t *seq_lens, void *scratch, float softmax_scale,
+                                            int32_t num_decoding_seqs, int32_t num_q_heads, int32_t num_kv_heads,
+                                            int32_t head_dim, int32_t num_layers, int32_t block_size,
+                                            int32_t cur_layer, int32_t max_blocks_per_seq, int32_t seq_block_size,
+                                            int32_t num_seq_blocks, int64_t o_tok_stride, int32_t dtype,
+                                            swl_stream_t stream) {
+    if (num_decoding_seqs == 0 || num_seq_blocks == 0) return num_decoding_seqs < 0 ? SWL_ERR_BAD_ARG : SWL_OK;
+    if (!row_ssq || ssq_parts <= 0 || hidden <= 0) return SWL_ERR_BAD_ARG;
+    if (ssq_parts > 8 || !(k_splits == 1 || k_splits == 2 || k_splits == 4)) return SWL_ERR_UNSUPPORTED;
+    return paged_attn_decode_qkv_impl(o, qkv_slabs, k_splits, cos_table, sin_table, pos_idx, k_cache, v_cache, block_table,
+                                      seq_ids, seq_lens, scratch, softmax_scale, num_decoding_seqs, num_q_heads,
+                                      num_kv_heads, head_dim, num_layers, block_size, cur_layer, max_blocks_per_seq,
+                                      seq_block_size, num_seq_blocks, o_tok_stride, dtype, stream, row_ssq, ssq_parts,
+                                      hidden, eps);
+}
+
+static int paged_attn_decode_qkv_impl(void *o, const float *qkv_slabs, int32_t k_splits, const void *cos_table,
+                                         const void *sin_table, const int32_t *pos_idx, void *k_cache,
+                                         void *v_cache, const int32_t *block_table, const int32_t *seq_ids,
+                                         const int32_t *seq_lens, void *scratch, float softmax_scale,
+                                         int32_t num_decoding_seqs, int32_t num_q_heads, int32_t num_kv_heads,
+                                         int32_t head_dim, int32_t num_layers, int32_t block_size,
+                                         int32_t cur_layer, int32_t max_blocks_per_seq, int32_t seq_block_size,
+                                         int32_t num_seq_blocks, int64_t o_tok_stride, int32_t dtype,
+                                         swl_stream_t stream, const float *row_ssq, int32_t ssq_parts, int32_t hidden,
+                                         float eps) {
     if (num_decoding_seqs < 0) return SWL_ERR_BAD_ARG;
     if (num_decoding_seqs == 0 || num_seq_blocks == 0) return SWL_OK;
     if (!o || !qkv_slabs || !cos_table || !sin_table || !k_cache || !v_cache || !block_table || !seq_ids ||
@@ -731,6 +804,10 @@ extern "C" int swl_paged_attn_decode_qkv(void *o, const float *qkv_slabs, int32_
     p.cos_t = cos_table;
     p.sin_t = sin_table;
     p.pos_idx = pos_idx;
+    p.row_ssq = row_ssq;
+    p.ssq_parts = ssq_parts;
+    p.hidden = hidden;
+    p.eps = eps;
     const int G = num_q_heads / num_kv_heads;
     int rc;
     SWL_DISPATCH_DTYPE(dtype, T, {

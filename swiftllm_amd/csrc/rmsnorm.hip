@@ -87,6 +87,46 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(T *__restrict__ x, T *__res
     }
 }
 
+// ---- deferred normalisation (decode fast path) --------------------------------------------------------------------
+// fused_add_rmsnorm needs a whole row before it can write anything (the 1/rms), so as a split-K consumer it runs one
+// workgroup per token: 32 workgroups on a 256-CU part, each pulling 131 KB of slabs — 4.6 us of a 130 us layer, twice
+// per layer. But the 1/rms is a per-row SCALAR and commutes with the projection that follows:
+//     rmsnorm(r) . W^T  =  rstd * ((r * w_norm) . W^T)
+// so this kernel only does the element-wise part, fully parallel over rows AND columns — reduce the slabs, add the
+// residual (same rounding as fused_add_rmsnorm: the rounded sum is stored to `residual`), write xs = round(r * w_norm)
+// and the per-chunk sums of squares of r — and the consumer GEMM / attention prologue multiplies its fp32 results by
+// rstd = 1/sqrt(sum(ssq)/hidden + eps) before their one rounding. Numerically this moves one rounding (the reference
+// rounds the normalised activations, rmsnorm.py:57-64; here the un-normalised r * w is rounded and the scale is applied
+// in fp32): a deviation of the same order as a GEMM's summation order, covered by the end-to-end parity tolerances.
+constexpr int kAddScaleThreads = 128;
+constexpr int kAddScaleChunk = kAddScaleThreads * 8; // columns per workgroup
+
+template <typename T>
+__global__ __launch_bounds__(kAddScaleThreads) void splitk_add_scale_kernel(
+    T *__restrict__ xs, T *__restrict__ residual, const T *__restrict__ w, const float *__restrict__ slabs, int ks,
+    int64_t slab_stride, float *__restrict__ ssq_out, int num_tokens, int hidden) {
+    __shared__ float red[kAddScaleThreads / 64];
+    const int part = blockIdx.x, row = blockIdx.y;
+    const int col = part * kAddScaleChunk + threadIdx.x * 8;
+    const int64_t off = static_cast<int64_t>(row) * hidden + col;
+    const vec8_t<T> wv = load8(w + col);
+    const vec8_t<T> rv = load8(residual + off);
+    vec8_t<T> xv = load8_splitk<T>(slabs, ks, slab_stride, off);
+    vec8_t<T> sv;
+    float ssq = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        xv[j] = add_t<T>(xv[j], rv[j]); // rounded to T, as stored (rmsnorm.py:54-57)
+        const float v = to_f(xv[j]);
+        ssq = fmaf(v, v, ssq);
+        sv[j] = to_t<T>(v * to_f(wv[j]));
+    }
+    store8(residual + off, xv);
+    store8(xs + off, sv);
+    ssq = block_allreduce_sum<kAddScaleThreads / 64>(ssq, red);
+    if (threadIdx.x == 0) ssq_out[static_cast<int64_t>(part) * num_tokens + row] = ssq;
+}
+
 template <typename T, bool FUSED_ADD>
 static int launch_rmsnorm(T *x, T *residual, const T *w, float eps, int64_t num_tokens, int hidden,
                           hipStream_t stream, const float *slabs = nullptr, int ks = 0) {
@@ -153,4 +193,28 @@ extern "C" int swl_splitk_fused_add_rmsnorm(void *x_out, void *residual, const v
                                             static_cast<const T *>(w), eps, num_tokens, hidden,
                                             static_cast<hipStream_t>(stream), slabs, k_splits);
     });
+}
+
+/* Deferred-normalisation split-K consumer (see splitk_add_scale_kernel): residual += round(sum_k slabs[k]);
+ * x_scaled = round(residual * w); ssq_out[hidden / 1024][num_tokens] = per-1024-column sums of squares of the updated
+ * residual rows. The 1/rms is applied by the consumer (swl_gemm_skinny_packed_silu_gate_rs, swl_paged_attn_decode_qkv_rs).
+ * hidden % 1024 == 0. Replaces fused_add_rmsnorm (reference rmsnorm.py:67-89) on the decode fast path. */
+extern "C" int swl_splitk_add_scale(void *x_scaled, void *residual, const void *w, const float *slabs, int32_t k_splits,
+                                    float *ssq_out, int64_t num_tokens, int32_t hidden, int32_t dtype,
+                                    swl_stream_t stream) {
+    if (num_tokens < 0 || hidden <= 0 || k_splits <= 0) return SWL_ERR_BAD_ARG;
+    if (num_tokens == 0) return SWL_OK;
+    if (hidden % swl::kAddScaleChunk) return SWL_ERR_UNSUPPORTED;
+    if (!x_scaled || !residual || !w || !slabs || !ssq_out || !swl::aligned16(x_scaled) || !swl::aligned16(residual) ||
+        !swl::aligned16(w) || !swl::aligned16(slabs))
+        return SWL_ERR_BAD_ARG;
+    if (num_tokens > 65535) return SWL_ERR_UNSUPPORTED;
+    const dim3 grid(hidden / swl::kAddScaleChunk, static_cast<unsigned>(num_tokens));
+    SWL_DISPATCH_DTYPE(dtype, T, {
+        hipLaunchKernelGGL((swl::splitk_add_scale_kernel<T>), grid, dim3(swl::kAddScaleThreads), 0,
+                           static_cast<hipStream_t>(stream), static_cast<T *>(x_scaled), static_cast<T *>(residual),
+                           static_cast<const T *>(w), slabs, k_splits, num_tokens * static_cast<int64_t>(hidden), ssq_out,
+                           static_cast<int>(num_tokens), hidden);
+    });
+    return swl::check_launch();
 }

@@ -56,6 +56,11 @@ class EngineConfig:
     # write-through + device-scope count + last-arriver reduce) costs ~6 us per projection, as much as the
     # kernel boundary it removes (139 vs 131 us per layer).
     fuse_decode_layer: bool = False
+    # Decode batches of <= 32 sequences: apply the RMSNorm scale AFTER the projection that consumes the normalised
+    # activations (it is a per-token scalar), so the residual-add + norm split-K consumers become element-wise kernels
+    # that fill the chip instead of one workgroup per token. Moves one rounding (the un-normalised
+    # activations are rounded, the scale is applied in fp32); needs hidden % 1024 == 0, else the exact path runs.
+    defer_rmsnorm: bool = True
     # Allocate the host swap pool in pinned memory (true async DMA for swap_blocks).
     pin_swap_memory: bool = True
 

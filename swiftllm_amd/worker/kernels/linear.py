@@ -164,10 +164,25 @@ def linear_splitk(a: torch.Tensor, w: torch.Tensor, always: bool = False):
     return linear(a, w, skinny=True)
 
 
-def linear_silu_gate(a: torch.Tensor, w_up_gate: torch.Tensor):
+def row_scaled_silu_gate_ok(a: torch.Tensor, w_up_gate: torch.Tensor) -> bool:
+    """Can linear_silu_gate take activations whose RMSNorm scale is pending (packed weight, <= 32 tokens)?"""
+    return _skinny_ok(a, w_up_gate) and w_up_gate.shape[0] % 64 == 0 and _packed_of(w_up_gate) is not None
+
+
+def linear_silu_gate(a: torch.Tensor, w_up_gate: torch.Tensor, row_scale=None):
     """The FFN's `silu_and_mul_inplace(linear(a, up_gate_proj))[:, :I]` in one launch for decode-sized
     batches: returns [T, I], or None when the shapes do not qualify (the caller then takes the two-op
-    path)."""
+    path). `row_scale` (kernels/rmsnorm.py: RowScalePending, `a` is its .x): the projection's fp32 results are
+    multiplied by the pending 1/rms of their token before they are rounded."""
+    if row_scale is not None:
+        assert row_scaled_silu_gate_ok(a, w_up_gate) and row_scale.ssq.shape == (row_scale.parts, a.shape[0])
+        m, k = a.shape
+        inter = w_up_gate.shape[0] // 2
+        out = torch.empty((m, inter), dtype=a.dtype, device=a.device)
+        _hip.call("swl_gemm_skinny_packed_silu_gate_rs", _hip.ptr(out), _hip.ptr(a), _hip.ptr(_packed_of(w_up_gate)),
+                  _hip.ptr(row_scale.ssq), row_scale.parts, row_scale.eps, m, inter, k, _row_stride(a), inter,
+                  _hip.dtype_code(a.dtype), _hip.stream())
+        return out
     if _mid_ok(a, w_up_gate) and a.shape[0] <= 64 and w_up_gate.shape[0] % 64 == 0:   # medium batch, packed weight
         m, k = a.shape
         inter = w_up_gate.shape[0] // 2

@@ -44,7 +44,7 @@ def paged_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tenso
 
 def paged_attention_from_qkv_splitk(partials, k_cache: torch.Tensor, v_cache: torch.Tensor,
                                     block_table: torch.Tensor, model_config, engine_config, infer_state,
-                                    cur_layer: int, o: torch.Tensor):
+                                    cur_layer: int, o: torch.Tensor, row_scale=None):
     """Pure-decode batches: rotary + KV-store + paged attention in one launch, fed by the split-K partial slabs
     of the fused qkv projection (kernels/linear.py: SplitKPartials). Same bits as
     rotary_embedding_and_store_kvcache_decode_from_splitk followed by paged_attention; q/k/v never exist as
@@ -65,6 +65,19 @@ def paged_attention_from_qkv_splitk(partials, k_cache: torch.Tensor, v_cache: to
         scratch = getattr(infer_state, "paged_attn_scratch", None)
         if scratch is None or scratch.numel() * scratch.element_size() < need:
             scratch = torch.empty(need // 4, dtype=torch.float32, device=o.device)
+    if row_scale is not None:
+        # the qkv projection ran on activations whose RMSNorm scale is pending (kernels/rmsnorm.py: RowScalePending):
+        # the prologue applies 1/rms to the fp32 slab sums before rounding them
+        assert partials.k_splits in (1, 2, 4) and row_scale.ssq.shape == (row_scale.parts, nd)
+        _hip.call("swl_paged_attn_decode_qkv_rs", _hip.ptr(o), _hip.ptr(partials.slabs), partials.k_splits,
+                  _hip.ptr(row_scale.ssq), row_scale.parts, row_scale.x.shape[1], row_scale.eps,
+                  _hip.ptr(infer_state.position_cos), _hip.ptr(infer_state.position_sin),
+                  _hip.ptr(infer_state.position_indices), _hip.ptr(k_cache), _hip.ptr(v_cache), _hip.ptr(block_table),
+                  _hip.ptr(infer_state.seq_ids), _hip.ptr(infer_state.decoding_seq_lens), _hip.ptr(scratch),
+                  infer_state.softmax_scale, nd, h, kvh, d, model_config.num_layers, engine_config.block_size,
+                  cur_layer, block_table.shape[1], infer_state.seq_block_size, nsb, token_stride(o, "o"),
+                  _hip.dtype_code(o.dtype), _hip.stream())
+        return
     _hip.call("swl_paged_attn_decode_qkv", _hip.ptr(o), _hip.ptr(partials.slabs), partials.k_splits,
               _hip.ptr(infer_state.position_cos), _hip.ptr(infer_state.position_sin),
               _hip.ptr(infer_state.position_indices), _hip.ptr(k_cache), _hip.ptr(v_cache), _hip.ptr(block_table),

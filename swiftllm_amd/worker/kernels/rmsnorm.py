@@ -45,3 +45,38 @@ def fused_add_rmsnorm_from_splitk(partials, residual_io: torch.Tensor, weight: t
               _hip.ptr(partials.slabs), partials.k_splits, m, n, _hip.dtype_code(partials.dtype),
               _hip.stream())
     return out
+
+
+# ---- deferred normalisation (decode fast path; csrc/rmsnorm.hip: splitk_add_scale_kernel) -----------------------------
+_ADD_SCALE_CHUNK = 1024      # kAddScaleChunk: columns per workgroup = granularity of the sums of squares
+_MAX_SSQ_PARTS = 8
+
+
+class RowScalePending:
+    """Activations whose RMSNorm scale is still pending: `x` = round(residual * norm_weight) [tokens, hidden], `ssq`
+    [parts, tokens] the per-1024-column sums of squares of the residual rows. The consumer projection multiplies its
+    fp32 results by 1/sqrt(sum(ssq)/hidden + eps) before rounding (linear_silu_gate / paged_attention_from_qkv_splitk)."""
+    __slots__ = ("x", "ssq", "parts", "eps")
+
+    def __init__(self, x: torch.Tensor, ssq: torch.Tensor, parts: int, eps: float):
+        self.x, self.ssq, self.parts, self.eps = x, ssq, parts, eps
+
+
+def deferred_norm_ok(num_tokens: int, hidden: int) -> bool:
+    return 0 < num_tokens <= 32 and hidden % _ADD_SCALE_CHUNK == 0 and hidden // _ADD_SCALE_CHUNK <= _MAX_SSQ_PARTS
+
+
+def add_scale_from_splitk(partials, residual_io: torch.Tensor, weight: torch.Tensor, eps: float) -> RowScalePending:
+    """The element-wise half of fused_add_rmsnorm on split-K slabs: residual <- round(sum slabs) + residual (same bits
+    as fused_add_rmsnorm_from_splitk); returns round(residual * weight) with the 1/rms pending. Fully parallel over
+    rows and columns (the row-wide reduction is what keeps fused_add_rmsnorm at one workgroup per token)."""
+    m, n = partials.shape
+    _check_rows(residual_io, "residual_io")
+    assert residual_io.shape == (m, n) and residual_io.dtype == partials.dtype == weight.dtype
+    assert deferred_norm_ok(m, n)
+    parts = n // _ADD_SCALE_CHUNK
+    xs = torch.empty((m, n), dtype=partials.dtype, device=residual_io.device)
+    ssq = torch.empty((parts, m), dtype=torch.float32, device=residual_io.device)
+    _hip.call("swl_splitk_add_scale", _hip.ptr(xs), _hip.ptr(residual_io), _hip.ptr(weight), _hip.ptr(partials.slabs),
+              partials.k_splits, _hip.ptr(ssq), m, n, _hip.dtype_code(partials.dtype), _hip.stream())
+    return RowScalePending(xs, ssq, parts, eps)

@@ -13,6 +13,11 @@ partial slabs (SplitKPartials) straight to the next kernel — fused qkv -> rota
 o_proj -> the FFN's fused_add_rmsnorm, down_proj -> the NEXT layer's fused_add_rmsnorm — so `forward`
 may return, and accept, a SplitKPartials in place of the activation tensor.
 
+Deferred RMSNorm (defer_rmsnorm, batches of <= 32 sequences, hidden % 1024 == 0): the residual-add + norm consumers of
+the o_proj / down_proj slabs only do the element-wise part, in a launch that fills the chip (add_scale_from_splitk);
+the per-token 1/rms is applied by the consumer of the normalised activations — the slab-fed attention prologue for the
+qkv projection, the SiLU-gate GEMM's epilogue for the FFN — in fp32, before its one rounding.
+
 Fused decode layer (fuse_decode_layer, batches of <= 32 sequences): the hand-offs themselves move into the
 GEMMs — qkv projection (+ attention norm on the fly) with rotary/KV-store in its epilogue, attention,
 o_proj with the residual add in its epilogue, up/gate (+ FFN norm on the fly) with SiLU-gate, down_proj with
@@ -23,7 +28,9 @@ import torch
 
 from ..kernels.linear import (NormPending, SplitKPartials, fused_layer_ok, linear, linear_add_residual,
                               linear_norm_silu_gate, linear_qkv_rope_store, linear_silu_gate, linear_splitk)
-from ..kernels.rmsnorm import fused_add_rmsnorm_inplace, fused_add_rmsnorm_from_splitk, rmsnorm_inplace
+from ..kernels.linear import row_scaled_silu_gate_ok
+from ..kernels.rmsnorm import (add_scale_from_splitk, deferred_norm_ok, fused_add_rmsnorm_inplace,
+                               fused_add_rmsnorm_from_splitk, rmsnorm_inplace)
 from ..kernels.rotary_emb import (rotary_embedding_inplace, rotary_embedding_and_store_kvcache_decode,
                                   rotary_embedding_and_store_kvcache_decode_from_splitk)
 from ..kernels.kvcache_mgmt import store_kvcache
@@ -40,6 +47,7 @@ class LlamaTransformerLayer:
         self.decoding_piggyback_stream = decoding_piggyback_stream
         self.layer_id = layer_id
         self.skinny = bool(getattr(engine_config, "use_skinny_gemm", False))
+        self._qkv_splits = None     # k-splits the skinny GEMM picks for the fused qkv projection (cached)
 
     def _split_qkv(self, qkv: torch.Tensor):
         cfg = self.model_config
@@ -69,12 +77,36 @@ class LlamaTransformerLayer:
             return self._forward_after_attn_norm(input_embds, residual_buf, k_cache, v_cache, block_table, st)
 
         # residual_buf <- input_embds + residual_buf ; input_embds <- rmsnorm(residual_buf)
+        row_scale = None
         if isinstance(input_embds, SplitKPartials):     # the previous layer's down projection, unreduced
-            input_embds = fused_add_rmsnorm_from_splitk(input_embds, residual_buf, w.attn_norm,
-                                                        cfg.rms_norm_eps)
+            if self._deferred_attn_norm_ok(st):
+                row_scale = add_scale_from_splitk(input_embds, residual_buf, w.attn_norm, cfg.rms_norm_eps)
+                input_embds = row_scale.x
+            else:
+                input_embds = fused_add_rmsnorm_from_splitk(input_embds, residual_buf, w.attn_norm,
+                                                            cfg.rms_norm_eps)
         else:
             fused_add_rmsnorm_inplace(input_embds, residual_buf, w.attn_norm, cfg.rms_norm_eps)
-        return self._forward_after_attn_norm(input_embds, residual_buf, k_cache, v_cache, block_table, st)
+        return self._forward_after_attn_norm(input_embds, residual_buf, k_cache, v_cache, block_table, st, row_scale)
+
+    def _slab_fed_attention_applies(self, st) -> bool:
+        """Pure-decode batch on the path `fused qkv slabs -> (rotary + KV store + paged attention)` in one launch."""
+        cfg, ecfg, w = self.model_config, self.engine_config, self.weight
+        return (self.skinny and st.num_prefill_seqs == 0 and st.num_decoding_seqs > 0 and not st.ignore_kvcache
+                and st.position_indices is not None and getattr(ecfg, "fuse_rope_kvstore", False)
+                and getattr(ecfg, "fuse_splitk_consumers", True) and w.qkv_proj is not None
+                and getattr(ecfg, "fuse_rope_into_attention", True) and cfg.head_dim in (32, 64, 128))
+
+    def _deferred_attn_norm_ok(self, st) -> bool:
+        """The attention norm's 1/rms can be left to the attention prologue: slab-fed attention with <= 4 qkv slabs."""
+        cfg, ecfg, w = self.model_config, self.engine_config, self.weight
+        if not (getattr(ecfg, "defer_rmsnorm", False) and self._slab_fed_attention_applies(st)
+                and deferred_norm_ok(st.num_decoding_seqs, cfg.hidden_size)):
+            return False
+        if self._qkv_splits is None:
+            from swiftllm_amd import _hip
+            self._qkv_splits = int(_hip.load().swl_gemm_skinny_choose_splits(w.qkv_proj.shape[0], w.qkv_proj.shape[1]))
+        return self._qkv_splits in (1, 2, 4)
 
     def _fused_decode_applies(self, st, residual_buf) -> bool:
         cfg, ecfg, w = self.model_config, self.engine_config, self.weight
@@ -107,7 +139,10 @@ class LlamaTransformerLayer:
         act = linear_norm_silu_gate(stream, w.ffn_norm, eps, w.up_gate_proj)
         return linear_add_residual(act, w.down_proj, residual_buf)
 
-    def _forward_after_attn_norm(self, input_embds, residual_buf, k_cache, v_cache, block_table, infer_state):
+    def _forward_after_attn_norm(self, input_embds, residual_buf, k_cache, v_cache, block_table, infer_state,
+                                 row_scale=None):
+        """`row_scale` (RowScalePending): `input_embds` is round(residual * attn_norm) with its 1/rms pending — only
+        ever passed when the slab-fed attention path below is taken (_deferred_attn_norm_ok)."""
         cfg, ecfg, w, st = self.model_config, self.engine_config, self.weight, infer_state
 
         pure_decode = st.num_prefill_seqs == 0 and st.num_decoding_seqs > 0
@@ -120,8 +155,9 @@ class LlamaTransformerLayer:
             qkv = linear_splitk(input_embds, w.qkv_proj, always=True)
             if isinstance(qkv, SplitKPartials):
                 paged_attention_from_qkv_splitk(qkv, k_cache, v_cache, block_table, cfg, ecfg, st, self.layer_id,
-                                                input_embds)
+                                                input_embds, row_scale=row_scale)
                 return self._forward_after_attention(input_embds, residual_buf, fast)
+        assert row_scale is None, "deferred RMSNorm reached a path that cannot apply it"
         if fast and fused_rope_store and w.qkv_proj is not None:
             qkv = linear_splitk(input_embds, w.qkv_proj)
             if isinstance(qkv, SplitKPartials):
@@ -170,6 +206,12 @@ class LlamaTransformerLayer:
         if fast:
             attn_out = linear_splitk(input_embds, w.o_proj)
             if isinstance(attn_out, SplitKPartials):
+                if (getattr(self.engine_config, "defer_rmsnorm", False) and deferred_norm_ok(*attn_out.shape)
+                        and row_scaled_silu_gate_ok(input_embds, w.up_gate_proj)):
+                    # element-wise add + scale (fills the chip); the FFN norm's 1/rms goes into the SiLU-gate GEMM
+                    pend = add_scale_from_splitk(attn_out, residual_buf, w.ffn_norm, cfg.rms_norm_eps)
+                    act = linear_silu_gate(pend.x, w.up_gate_proj, row_scale=pend)
+                    return linear_splitk(act, w.down_proj)
                 attn_out = fused_add_rmsnorm_from_splitk(attn_out, residual_buf, w.ffn_norm, cfg.rms_norm_eps)
             else:
                 fused_add_rmsnorm_inplace(attn_out, residual_buf, w.ffn_norm, cfg.rms_norm_eps)

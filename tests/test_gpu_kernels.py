@@ -849,3 +849,121 @@ def test_gemm_packed_mid_silu_gate_equals_two_ops(dtype, M, I, Kd):
               _hip.stream())
     K().silu_and_mul_inplace(two)
     assert torch.equal(fused, two[:, :I])
+
+
+# ---- deferred RMSNorm (decode fast path) ---------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,hidden", [(32, 4096), (1, 4096), (7, 1024), (5, 8192)])
+def test_add_scale_from_splitk(dtype, M, hidden):
+    """The element-wise split-K consumer: residual gets the bits fused_add_rmsnorm_from_splitk gives it, x_scaled is
+    exactly round(residual * w), and the sums of squares add up to the row's (fp64 reference, fp32 summation order)."""
+    from swiftllm_amd.worker.kernels.linear import linear_splitk, SplitKPartials
+    from swiftllm_amd.worker.kernels.rmsnorm import add_scale_from_splitk, fused_add_rmsnorm_from_splitk
+    g = gen(M + hidden)
+    x = torch.randn(M, 4096, generator=g).to(dtype).cuda()
+    w = (torch.randn(hidden, 4096, generator=g) * 0.02).to(dtype).cuda()
+    res = torch.randn(M, hidden, generator=g).to(dtype).cuda()
+    nw = (1 + 0.1 * torch.randn(hidden, generator=g)).to(dtype).cuda()
+    part = linear_splitk(x, w, always=True)
+    assert isinstance(part, SplitKPartials)
+    r_exact = res.clone()
+    fused_add_rmsnorm_from_splitk(part, r_exact, nw, 1e-5)
+    r_def = res.clone()
+    pend = add_scale_from_splitk(part, r_def, nw, 1e-5)
+    assert torch.equal(r_def, r_exact)
+    assert torch.equal(pend.x, (r_def.float() * nw.float()).to(dtype))
+    assert pend.ssq.shape == (hidden // 1024, M)
+    want = r_def.double().pow(2).view(M, hidden // 1024, 1024).sum(-1).T
+    assert torch.allclose(pend.ssq.double(), want, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [1, 32])
+def test_deferred_rmsnorm_ffn_matches_exact_path(dtype, M):
+    """o_proj slabs -> [add + scale] -> SiLU-gate GEMM with the 1/rms in its epilogue, against the exact-rounding path
+    (fused_add_rmsnorm, then the same GEMM) and against an fp64 evaluation of the FFN input/gate: the deferred path
+    moves ONE rounding (un-normalised activations are rounded instead of normalised ones), so the two agree to a few
+    ulps of the storage dtype and are equally far from the fp64 value."""
+    from swiftllm_amd.worker.kernels.linear import linear_splitk, linear_silu_gate, pack_weight
+    from swiftllm_amd.worker.kernels.rmsnorm import add_scale_from_splitk, fused_add_rmsnorm_from_splitk
+    g = gen(M * 3 + 1)
+    h, inter = 4096, 14336
+    a = torch.randn(M, h, generator=g).to(dtype).cuda()
+    wo = (torch.randn(h, h, generator=g) * 0.02).to(dtype).cuda()
+    res = (3 * torch.randn(M, h, generator=g)).to(dtype).cuda()
+    nw = (1 + 0.1 * torch.randn(h, generator=g)).to(dtype).cuda()
+    wug = (torch.randn(2 * inter, h, generator=g) * 0.02).to(dtype).cuda()
+    pack_weight(wug)
+    part = linear_splitk(a, wo)
+    r1 = res.clone()
+    xn = fused_add_rmsnorm_from_splitk(part, r1, nw, 1e-5)
+    exact = linear_silu_gate(xn, wug)
+    r2 = res.clone()
+    pend = add_scale_from_splitk(part, r2, nw, 1e-5)
+    got = linear_silu_gate(pend.x, wug, row_scale=pend)
+    assert torch.equal(r1, r2)
+    # fp64 value of up * silu(gate) on the un-rounded normalised activations
+    rd = r1.double()
+    xd = rd / torch.sqrt(rd.pow(2).mean(-1, keepdim=True) + 1e-5) * nw.double()
+    ug = xd @ wug.double().T
+    ref = ug[:, :inter] * (ug[:, inter:] / (1 + torch.exp(-ug[:, inter:])))
+    eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    scale = ref.abs().amax(dim=1, keepdim=True).clamp(min=1e-3)
+    err_exact = ((exact.double() - ref).abs() / scale).max().item()
+    err_def = ((got.double() - ref).abs() / scale).max().item()
+    print(f"\n[deferred rmsnorm, FFN, {dtype}, M={M}] max |err| / row max: exact path {err_exact:.3e}, deferred {err_def:.3e} (eps {eps:.1e})")
+    assert err_def <= 3 * eps and err_def <= 1.5 * err_exact + eps
+    assert ((got.double() - exact.double()).abs() / scale).max().item() <= 3 * eps
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sbs", [64, 1024])
+def test_deferred_rmsnorm_attention_matches_exact_path(dtype, sbs):
+    """down_proj slabs -> [add + scale] -> qkv slabs -> slab-fed attention with the 1/rms applied in its prologue,
+    against fused_add_rmsnorm -> the same projection -> the same attention: rotated k / v written to the pools within
+    one rounding step of the exact path's, attention output within the storage dtype's resolution."""
+    from swiftllm_amd.worker.kernels.linear import linear_splitk
+    from swiftllm_amd.worker.kernels.paged_attn import paged_attention_from_qkv_splitk
+    from swiftllm_amd.worker.kernels.rmsnorm import add_scale_from_splitk, fused_add_rmsnorm_from_splitk
+    H, KVH, D, hid = 32, 8, 128, 4096
+    g = gen(sbs + 17)
+    L, layer = 2, 1
+    lens = [1, 15, 16, 17, 63, 64, 65, 300, 129]
+    nd = len(lens)
+    _, kc, vc, bt, seq_ids = _paged_case(g, H, KVH, D, L, lens, dtype, layer)
+    n = (H + 2 * KVH) * D
+    a = torch.randn(nd, 14336, generator=g).to(dtype).cuda()
+    wdown = (torch.randn(hid, 14336, generator=g) * 0.01).to(dtype).cuda()
+    res = (2 * torch.randn(nd, hid, generator=g)).to(dtype).cuda()
+    nw = (1 + 0.1 * torch.randn(hid, generator=g)).to(dtype).cuda()
+    wqkv = (torch.randn(n, hid, generator=g) * (hid ** -0.5)).to(dtype).cuda()
+    ang = torch.rand(512, D // 2, generator=g) * 6.28
+    st = _paged_state(lens, seq_ids, sbs, D, "cuda")
+    st.position_cos, st.position_sin = torch.cos(ang).to(dtype).cuda(), torch.sin(ang).to(dtype).cuda()
+    st.position_indices = torch.tensor([v - 1 for v in lens], dtype=torch.int32, device="cuda")
+    mc, ec = NS(num_q_heads=H, num_kv_heads=KVH, head_dim=D, num_layers=L), NS(block_size=16)
+    btc = bt.cuda()
+    down = linear_splitk(a, wdown)
+    # exact path
+    r1 = res.clone()
+    xn = fused_add_rmsnorm_from_splitk(down, r1, nw, 1e-5)
+    kc1, vc1 = kc.cuda(), vc.cuda()
+    o1 = torch.zeros(nd, H * D, dtype=dtype, device="cuda")
+    paged_attention_from_qkv_splitk(linear_splitk(xn, wqkv, always=True), kc1, vc1, btc, mc, ec, st, layer, o1)
+    # deferred path
+    r2 = res.clone()
+    pend = add_scale_from_splitk(down, r2, nw, 1e-5)
+    kc2, vc2 = kc.cuda(), vc.cuda()
+    o2 = torch.zeros(nd, H * D, dtype=dtype, device="cuda")
+    paged_attention_from_qkv_splitk(linear_splitk(pend.x, wqkv, always=True), kc2, vc2, btc, mc, ec, st, layer, o2,
+                                    row_scale=pend)
+    eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    assert torch.equal(r1, r2)
+    dk = (kc2.float() - kc1.float()).abs().max().item()
+    dv = (vc2.float() - vc1.float()).abs().max().item()
+    do = (o2.float() - o1.float()).abs().max().item()
+    print(f"\n[deferred rmsnorm, attention, {dtype}, sbs={sbs}] max |dk| {dk:.3e} |dv| {dv:.3e} |do| {do:.3e}")
+    kmax = kc1.float().abs().max().item()
+    assert dk <= 4 * eps * kmax and dv <= 4 * eps * kmax
+    assert do <= 4 * eps * max(1.0, o1.float().abs().max().item())
+    assert not torch.equal(kc2.cpu(), kc)

@@ -4,7 +4,8 @@ Model: Llama-3-8B layer geometry (hidden 4096, 32 q / 8 kv heads of 128, FFN 143
 8k vocabulary (so the CPU side stays small). Workloads: BASELINE.json configs[1] (batch 1, 1024-token prompt,
 greedy decode) and a configs[2]-shaped ragged batch of 32 (lengths 1..1024). The HIP data plane — default path,
 hipGraph replay, row-major (unpacked) decode weights — is compared with oracle/ref_model.py, which is pinned to the
-reference's own run on the tiny golden (tests/test_oracle_golden.py), in BOTH decode-score modes:
+reference's own run on the tiny golden (tests/test_oracle_golden.py), in BOTH decode-score modes (the default path
+defers the RMSNorm scale into the consuming projection, `exact_rmsnorm_rounding` keeps the reference's rounding points):
   * "fp32": exact scores (the reference's commented eager restatement, paged_attn.py:224-259);
   * "ref" : the Triton kernel's fp16 products / fp16 sum / fp16 scale (paged_attn.py:17,72-73).
 The distance between those two oracles is the noise floor of the reference itself at this size: it is measured
@@ -42,7 +43,8 @@ CASES = {
                           1024, 2, 31, 48, 300, 700, 800, 5, 1023, 256, 255, 77, 450, 999, 10, 129], 5),
 }
 VARIANTS = (("default", dict()), ("hipgraph", dict(use_hip_graph=True)),
-            ("row_major_weights", dict(pack_decode_weights=False)))
+            ("row_major_weights", dict(pack_decode_weights=False)),
+            ("exact_rmsnorm_rounding", dict(defer_rmsnorm=False)))
 
 
 def _ulp(x: torch.Tensor, dtype) -> torch.Tensor:

@@ -7,10 +7,11 @@ shipped to the GPU box by gpurun; the tests skip when they are absent. The refer
 process (`python -m oracle.ref_triton ...`): its package is called `swiftllm` like this repo's import alias.
 
 Tolerances (fp16): copies bit-exact; rmsnorm / silu <= 1-2 ulp (fp32 reduction order, exp implementation); rotary
-<= 1 ulp (compiled Triton may contract fp16 mul+add into fma); decode attention <= 4e-3 (the
+within one rounding of the products (compiled Triton contracts fp16 mul+add into fma); decode attention <= 4e-3 (the
 reference rounds scores to fp16, paged_attn.py:72-73 — ours is closer to the exact value); prefill attention
 <= 2e-3; whole forward: greedy ids identical except at near-ties below the measured logit distance, logits within
-2 ulp of the row scale (the 1e-3 of the north star holds where logits are O(0.1): the tiny model).
+8 ulp of the row scale at Llama-3-8B width — the reference's own fp16-score noise there is ~5 ulp — and the north star's
+1e-3 where logits are O(0.1): the tiny model.
 """
 import json
 import os
@@ -116,8 +117,18 @@ def test_reference_triton_kernels_vs_hip_per_operator(tmp_path):
     c = cases["rotary"]
     gq, gk = c["q"].cuda(), c["k"].cuda()
     k.rotary_embedding_inplace(gq, gk, NS(position_cos=c["cos"].cuda(), position_sin=c["sin"].cuda()))
-    report["rotary_q_ulp"] = ulp_diff_fp16(gq.cpu(), ref["rotary"]["q"])
-    report["rotary_k_ulp"] = ulp_diff_fp16(gk.cpu(), ref["rotary"]["k"])
+    # compiled Triton contracts the fp16 multiply-add of the rotation into an fma (one rounding fewer than the
+    # interpreter run our kernel reproduces bit for bit): the results differ by up to one rounding of the PRODUCTS,
+    # which under cancellation is many ulps of the small difference — so the bound is on |delta| relative to the
+    # operands, eps_fp16 * (|x0| + |x1|), not in ulps of the result
+    def rot_excess(got, want, x):
+        half = x.shape[-1] // 2
+        mag = x[..., :half].float().abs() + x[..., half:].float().abs()
+        bound = 2.0 ** -10 * torch.cat([mag, mag], dim=-1)
+        return ((got.float() - want.float()).abs() - bound).max().item()
+    report["rotary_q_excess"] = rot_excess(gq.cpu(), ref["rotary"]["q"], c["q"])
+    report["rotary_k_excess"] = rot_excess(gk.cpu(), ref["rotary"]["k"], c["k"])
+    report["rotary_q_max_abs"] = (gq.cpu().float() - ref["rotary"]["q"].float()).abs().max().item()
     # paged attention
     o = torch.zeros_like(q).cuda()
     st = NS(num_decoding_seqs=len(lens), num_prefill_seqs=0, seq_block_size=256, num_seq_blocks=-(-max(lens) // 256),
@@ -151,7 +162,7 @@ def test_reference_triton_kernels_vs_hip_per_operator(tmp_path):
         json.dump(report, f, indent=1)
     assert report["rmsnorm_ulp"] <= 1 and report["fused_add_rmsnorm_ulp"] <= 1
     assert report["silu_ulp"] <= 2
-    assert report["rotary_q_ulp"] <= 1 and report["rotary_k_ulp"] <= 1
+    assert report["rotary_q_excess"] <= 0 and report["rotary_k_excess"] <= 0
     assert report["paged_attention_max_abs"] <= 4e-3
     assert report["prefill_attention_max_abs"] <= 2e-3
 
@@ -218,5 +229,8 @@ def test_reference_forward_vs_hip_forward(tmp_path, width):
         assert worst_abs <= 1e-3, worst_abs          # the north star's bar, where logits are O(0.1)
         assert not mism, mism
     else:
-        assert worst_ulp <= 2.0, (worst_ulp, worst_abs)
+        # At this width the REFERENCE is the noisy side: its fp16 score path (paged_attn.py:72-73) puts it 4.75-5.5 ulp
+        # of the row scale from the exact-score oracle (measured by tests/test_gpu_parity_fullwidth.py on this same
+        # model geometry), ours sits <= 2 ulp from it. Distance between the two <= the sum.
+        assert worst_ulp <= 8.0, (worst_ulp, worst_abs)
         assert all(gap <= 2 * worst_abs for _, _, gap in mism), mism

@@ -922,7 +922,7 @@ def test_deferred_rmsnorm_attention_matches_exact_path(dtype, sbs):
     """down_proj slabs -> [add + scale] -> qkv slabs -> slab-fed attention with the 1/rms applied in its prologue,
     against fused_add_rmsnorm -> the same projection -> the same attention: rotated k / v written to the pools within
     one rounding step of the exact path's, attention output within the storage dtype's resolution."""
-    from swiftllm_amd.worker.kernels.linear import linear_splitk
+    from swiftllm_amd.worker.kernels.linear import linear_splitk, SplitKPartials
     from swiftllm_amd.worker.kernels.paged_attn import paged_attention_from_qkv_splitk
     from swiftllm_amd.worker.kernels.rmsnorm import add_scale_from_splitk, fused_add_rmsnorm_from_splitk
     H, KVH, D, hid = 32, 8, 128, 4096
@@ -944,6 +944,8 @@ def test_deferred_rmsnorm_attention_matches_exact_path(dtype, sbs):
     mc, ec = NS(num_q_heads=H, num_kv_heads=KVH, head_dim=D, num_layers=L), NS(block_size=16)
     btc = bt.cuda()
     down = linear_splitk(a, wdown)
+    # (the slabs live in the shared split-K workspace, which the qkv projections below reuse: keep a private copy)
+    down = SplitKPartials(down.slabs[:down.k_splits * nd * hid].clone(), down.k_splits, nd, hid, down.dtype)
     # exact path
     r1 = res.clone()
     xn = fused_add_rmsnorm_from_splitk(down, r1, nw, 1e-5)

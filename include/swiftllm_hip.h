@@ -361,6 +361,28 @@ int swl_paged_attn_decode_qkv_rs(void *o, const float *qkv_slabs, int32_t k_spli
                                  int32_t cur_layer, int32_t max_blocks_per_seq, int32_t seq_block_size,
                                  int32_t num_seq_blocks, int64_t o_tok_stride, int32_t dtype, swl_stream_t stream);
 
+/* ---- decode projections with K split inside the workgroup (csrc/gemm_wgk.hip) ------------------------------------
+ * The hidden-by-hidden projections of a decode layer (reference linear.py:3-12 at transformer_layer.py:54-56 and :117)
+ * for M <= 32 tokens on a packed weight (swl_gemm_pack_weight): one workgroup owns 32 rows of W for all of K, its 8
+ * waves split K and add their accumulators through LDS in wave order — the bits of the 8-slab split-K sum — so the
+ * projection needs no slab workspace and no consumer launch. N % 32 == 0, K % 1024 == 0 (swl_gemm_wgk_supported).
+ *   swl_gemm_wgk: out[M, N] = round(rstd[m] * (x . W^T)) in the storage dtype, or unrounded fp32 when out_fp32 != 0 (the
+ *     single "slab" swl_paged_attn_decode_qkv takes with k_splits = 1). row_ssq == NULL: rstd = 1; else the deferred
+ *     RMSNorm scale rstd[m] = 1/sqrt(sum_{p < ssq_parts} row_ssq[p * ssq_stride + m] / K + eps), ssq_parts <= 16
+ *     (swl_splitk_add_scale's output: ssq_stride = M).
+ *   swl_gemm_wgk_add_scale: o_proj + the element-wise half of the FFN norm (transformer_layer.py:117-120, rmsnorm.py:
+ *     67-89): residual[m, :] += round(x . W^T) (stored rounded, as the reference stores it); x_scaled = round(residual *
+ *     norm_w); ssq_out[N/32][32] = per-32-column sums of squares of the updated residual rows (rows >= M unwritten) —
+ *     the same arithmetic as swl_gemm_skinny_packed_partial (k_splits = 8) + swl_splitk_add_scale, bit for bit on
+ *     residual and x_scaled. Consumer: swl_gemm_skinny_packed_silu_gate_rs with ssq_parts = N/32, ssq_stride = 32. */
+int swl_gemm_wgk_supported(int32_t M, int32_t N, int32_t K);
+int swl_gemm_wgk(void *out, int32_t out_fp32, const void *x, const void *w_packed, const float *row_ssq,
+                 int32_t ssq_parts, int32_t ssq_stride, float eps, int32_t M, int32_t N, int32_t K,
+                 int64_t x_row_stride, int64_t out_row_stride, int32_t dtype, swl_stream_t stream);
+int swl_gemm_wgk_add_scale(void *x_scaled, void *residual, float *ssq_out, const void *norm_w, const void *x,
+                           const void *w_packed, int32_t M, int32_t N, int32_t K, int64_t x_row_stride, int32_t dtype,
+                           swl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

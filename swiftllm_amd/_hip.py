@@ -78,6 +78,8 @@ SIGNATURES = {
                                      _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I32, _P],
     "swl_splitk_rotary_store_kv_decode": [_P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32,
                                           _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _P],
+    "swl_gemm_wgk": [_P, _I32, _P, _P, _P, _I32, _I32, _F32, _I32, _I32, _I32, _I64, _I64, _I32, _P],
+    "swl_gemm_wgk_add_scale": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I64, _I32, _P],
 }
 # Entry points that do not follow the "int rc = f(...)" convention.
 _SPECIAL = {
@@ -88,6 +90,7 @@ _SPECIAL = {
     "swl_gemm_skinny_workspace_bytes": ([_I32, _I32, _I32], ctypes.c_size_t),
     "swl_gemm_skinny_choose_splits": ([_I32, _I32], _I32),
     "swl_gemm_packed_mid_choose_splits": ([_I32, _I32, _I32], _I32),
+    "swl_gemm_wgk_supported": ([_I32, _I32, _I32], _I32),
 }
 
 _lock = threading.Lock()

@@ -24,6 +24,7 @@ SOURCES = [
     "block_table.hip",
     "swap_blocks.hip",
     "gemm_skinny.hip",
+    "gemm_wgk.hip",
     "argmax.hip",
 ]
 HEADERS = ["swl_common.h", os.path.join(ROOT, "include", "swiftllm_hip.h")]

@@ -501,7 +501,12 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
     }
 }
 
-// grid (H, Bd), one wave per (sequence, q-head): LSE-weighted merge of the partials.
+// grid (H, Bd), one wave per (sequence, q-head): LSE-weighted merge of the partials (reference paged_attn.py:
+// 108-150). Latency is all there is to this kernel (n <= a few dozen partials of 512 B each), so nothing in it may
+// serialise on memory: the n log-sum-exps arrive in ONE load (lane s holds partial s), the weights are computed once
+// per lane and handed out with v_readlane, and the partial outputs are requested eight at a time before the first
+// FMA — two round trips in all. (r01: one dependent load pair per partial, 10.9 us at 16 partials = more than the
+// attention itself at batch 1; profiles/r02d.) The weighted sum keeps the partial order.
 template <typename T, int D>
 __global__ __launch_bounds__(64) void paged_attn_phase2_kernel(
     T *__restrict__ o, const float *__restrict__ mid_o, const float *__restrict__ mid_lse,
@@ -513,29 +518,52 @@ __global__ __launch_bounds__(64) void paged_attn_phase2_kernel(
     const int len = seq_lens[seq];
     const int n = (len + seq_block_size - 1) / seq_block_size;
     const int64_t base = (static_cast<int64_t>(seq) * H + head) * num_seq_blocks;
+    constexpr int VD = (D + 63) / 64;
+    constexpr int U = 8;
 
-    float M = kNegBig;
-    for (int s = lane; s < n; s += 64) M = fmaxf(M, mid_lse[base + s]);
+    // first requests: the log-sum-exps of up to 64 partials and the first U partial outputs
+    float lse = lane < n ? mid_lse[base + lane] : kNegBig;
+    float v[U][VD];
+    auto request = [&](int s0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int q = 0; q < VD; ++q) {
+                const int d = lane + q * 64;
+                v[u][q] = (s0 + u < n && d < D) ? mid_o[(base + s0 + u) * D + d] : 0.f;
+            }
+    };
+    request(0);
+    float M = lse;
+    for (int s = lane + 64; s < n; s += 64) M = fmaxf(M, mid_lse[base + s]); // (> 64 partials: 128k-token sequences)
     M = wave_allreduce_max(M);
 
-    constexpr int VD = (D + 63) / 64;
     float acc[VD];
 #pragma unroll
-    for (int v = 0; v < VD; ++v) acc[v] = 0.f;
+    for (int q = 0; q < VD; ++q) acc[q] = 0.f;
     float Lsum = 0.f;
-    for (int s = 0; s < n; ++s) {
-        const float w = fast_exp2(mid_lse[base + s] - M);
-        Lsum += w;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        if (c0 > 0) lse = c0 + lane < n ? mid_lse[base + c0 + lane] : kNegBig;
+        const float w_lane = c0 + lane < n ? fast_exp2(lse - M) : 0.f;
+        Lsum += w_lane;
+        const int lim = min(64, n - c0);
+        for (int s0 = 0; s0 < lim; s0 += U) {
+            if (c0 + s0 > 0) request(c0 + s0);
 #pragma unroll
-        for (int v = 0; v < VD; ++v) {
-            const int d = lane + v * 64;
-            if (d < D) acc[v] = fmaf(w, mid_o[(base + s) * D + d], acc[v]);
+            for (int u = 0; u < U; ++u) {
+                // lanes beyond the last partial hold w = 0 and v = 0: no guard needed
+                const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w_lane),
+                                                                                    (s0 + u) & 63));
+#pragma unroll
+                for (int q = 0; q < VD; ++q) acc[q] = fmaf(w, v[u][q], acc[q]);
+            }
         }
     }
+    Lsum = wave_allreduce_sum(Lsum);
 #pragma unroll
-    for (int v = 0; v < VD; ++v) {
-        const int d = lane + v * 64;
-        if (d < D) o[seq * o_tok_stride + static_cast<int64_t>(head) * D + d] = to_t<T>(acc[v] / Lsum);
+    for (int q = 0; q < VD; ++q) {
+        const int d = lane + q * 64;
+        if (d < D) o[seq * o_tok_stride + static_cast<int64_t>(head) * D + d] = to_t<T>(acc[q] / Lsum);
     }
 }
 

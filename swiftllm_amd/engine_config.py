@@ -64,6 +64,21 @@ class EngineConfig:
     # Allocate the host swap pool in pinned memory (true async DMA for swap_blocks).
     pin_swap_memory: bool = True
 
+    # Tokens per KV block the HIP kernels are built for (csrc/paged_attn.hip kBlk, kvcache.hip): one 16-token block
+    # of a 128-wide head is 4 KiB = one wave-wide 16 B/lane load x 4.
+    SUPPORTED_BLOCK_SIZE = 16
+
+    def __post_init__(self):
+        # The reference takes block_size as a Triton constexpr (paged_attn.py:27) and its CLI default is 16
+        # (engine_config.py:37-42). Here the block is a compile-time tile; anything else is refused on the host,
+        # before any memory is allocated, instead of surfacing as SWL_ERR_UNSUPPORTED from the first decode step.
+        if int(self.block_size) != self.SUPPORTED_BLOCK_SIZE:
+            raise ValueError(
+                f"block_size={self.block_size} is not supported: the MI355X kernels are built for "
+                f"{self.SUPPORTED_BLOCK_SIZE}-token KV blocks (pass --block-size {self.SUPPORTED_BLOCK_SIZE})")
+        if self.dtype not in ("float16", "bfloat16"):
+            raise ValueError(f"dtype must be 'float16' or 'bfloat16', got {self.dtype!r}")
+
     @staticmethod
     def add_cli_args(parser: argparse.ArgumentParser):
         """Add the engine's CLI flags (same flag names as the reference, engine_config.py:25-84)."""

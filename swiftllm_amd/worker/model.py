@@ -115,6 +115,18 @@ class LlamaModel:
         by load_weights; call again after modifying weights in place."""
         ecfg = self.engine_config
         if getattr(ecfg, "pack_decode_weights", False) and getattr(ecfg, "use_skinny_gemm", False):
+            # The packed copies double the projection weights' footprint. If that would leave less than a quarter
+            # of the usable HBM for activations + KV pool, keep only the row-major weights and say so (a 70B model
+            # is 140 GB: it fits the 288 GB part once, not twice).
+            proj_bytes = sum(t.numel() * t.element_size() for t in self.weight.projection_tensors())
+            free_b, total_b = torch.cuda.mem_get_info(self.device)
+            usable = total_b * float(getattr(ecfg, "gpu_mem_utilization", 0.97)) - (total_b - free_b)
+            if proj_bytes > 0.75 * usable:
+                print(f"[Model] pack_decode_weights disabled: a second {proj_bytes / 2**30:.1f} GiB copy of the "
+                      f"projection weights would leave {max(0.0, usable - proj_bytes) / 2**30:.1f} GiB for the KV "
+                      f"pool; decode GEMMs stream the row-major weights instead", flush=True)
+                ecfg.pack_decode_weights = False
+                return
             pack_decode_weights(self.weight)
 
     @torch.inference_mode()

@@ -98,6 +98,16 @@ class LlamaWeight:
             layer.load(getter, device, fuse_qkv)
 
 
+    def projection_tensors(self) -> list:
+        """Every weight matrix a decode step streams through a GEMM (lm_head + the per-layer projections that exist
+        under the current fuse_qkv setting) — the tensors pack_decode_weights gives a second, MFMA-ordered copy."""
+        out = [getattr(self, "lm_head", None)]
+        for layer in self.layers:
+            out += [getattr(layer, a, None) for a in ("qkv_proj", "q_proj", "k_proj", "v_proj", "o_proj",
+                                                      "up_gate_proj", "down_proj")]
+        return [t for t in out if t is not None]
+
+
 # ---- checkpoint readers --------------------------------------------------------------------------
 def _dummy_getter(dtype: torch.dtype, device: torch.device) -> Getter:
     def get(spec: WeightSpec) -> torch.Tensor:
@@ -290,11 +300,7 @@ def pack_decode_weights(weight: "LlamaWeight") -> int:
     the 288 GB). Returns the bytes added. Call again after changing weights in place."""
     from .kernels.linear import pack_weight, packable
     added = 0
-    tensors = [weight.lm_head]
-    for layer in weight.layers:
-        tensors += [getattr(layer, a, None) for a in ("qkv_proj", "q_proj", "k_proj", "v_proj", "o_proj",
-                                                      "up_gate_proj", "down_proj")]
-    for t in tensors:
+    for t in weight.projection_tensors():
         if packable(t):
             added += pack_weight(t).numel() * t.element_size()
     return added

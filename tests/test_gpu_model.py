@@ -327,4 +327,6 @@ def test_full_width_layers_fast_path_equals_reference_op_sequence(tmp_path, dtyp
                 if x != y:
                     top2 = ref_logits[step][seq].topk(2).values
                     assert float(top2[0] - top2[1]) <= 8 * eps * float(top2[0].abs().clamp(min=1.0)), (name, step, seq)
-    assert results["default"] == results["hipgraph"]
+    # (no bit-equality between "default" and "hipgraph": since r02 graph mode rounds seq_block_size up to a power of
+    # two to bound the graph cache (model.py:_decode_graph), so the attention splits — and with them the fp32
+    # summation order — differ from the eager plan's; both are held to the reference run above.)

@@ -336,3 +336,16 @@ def test_streaming_loader_reads_sharded_checkpoints(tmp_path):
     (tmp_path / "model.safetensors.index.json").unlink()
     with pytest.raises(AssertionError, match="index.json not found"):
         load_weights(mc, torch.float16, str(tmp_path), device="cpu")
+
+
+def test_engine_config_rejects_unsupported_block_size():
+    """block_size is a compile-time tile of the HIP kernels (16); the reference takes it as a Triton constexpr
+    (paged_attn.py:27, engine_config.py:37-42). Anything else must be refused on the host with a clear message."""
+    from swiftllm_amd.engine_config import EngineConfig
+    base = dict(model_path="", use_dummy=True, gpu_mem_utilization=0.5, num_cpu_blocks=4,
+                max_seqs_in_block_table=8, max_blocks_per_seq=8, max_batch_size=4, max_tokens_in_batch=64)
+    EngineConfig(block_size=16, **base)
+    with pytest.raises(ValueError, match="block_size=32"):
+        EngineConfig(block_size=32, **base)
+    with pytest.raises(ValueError, match="dtype"):
+        EngineConfig(block_size=16, dtype="float32", **base)

@@ -377,6 +377,7 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_skinny_kernel(
         process(wa, xa);
     }
 
+    mfma_results_ready<8>(acc); // acc comes straight out of the K loop (swl_common.h)
     gemm_epilogue<T, MODE, EPI != kEpiNone>(acc, out_, &lds[0][0][0], 2 * 32 * kKT, wave, lane, is_gate, tile_ok, col0, n0,
                            ksplit, M, N, out_stride);
     // (fused launches have N % 128 == 0: no wave left above, every thread reaches the barriers)
@@ -557,6 +558,7 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_skinny_ring_kernel(
 #undef SWL_ISSUE
 #undef SWL_STAGE_X
 #undef SWL_PROCESS
+    mfma_results_ready<8>(acc); // acc comes straight out of the K loop (swl_common.h)
     if constexpr (PACKED) {
         // no W tiles in LDS: the SiLU-gate exchange (32 x 40 elements per wave) reuses the x buffers once every
         // wave is done reading them
@@ -1160,6 +1162,9 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_packed_mt_kernel(
 #undef SWL_MT_ISSUE_X
 #undef SWL_MT_STAGE_X
 #undef SWL_MT_PROCESS
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) mfma_results_tie(acc[mt]);
+    mfma_results_ready<8>(acc[MT - 1]); // acc comes straight out of the K loop (swl_common.h)
     if constexpr (MODE == kGemmSiluGate) {
         // same rounding points as linear -> silu_and_mul_inplace: projection rounded to T, silu in fp32 rounded to
         // T, product in T. Exchange tile of (gate wave w, token block mt): 32 x 40 elements in the x buffers.

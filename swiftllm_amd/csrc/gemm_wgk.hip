@@ -173,6 +173,7 @@ __global__ __launch_bounds__(kWgkWaves * 64, 1) void gemm_wgk_kernel(WgkArgs a) 
 
     // ---- in-workgroup reduction: acc[r] = out^T[n = (r&3) + 8*(r>>2) + 4*hf][m = l32] -> red[wave][m][n] ----
     // (a wave's image goes into its OWN x tile: its LDS reads above were issued before these writes, in order)
+    mfma_results_ready<8>(acc); // acc is stored by DS instructions next (swl_common.h)
     float *red = reinterpret_cast<float *>(xl);
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {

@@ -81,6 +81,16 @@ __device__ __forceinline__ void attend_block(const vec8_t<T> (&qv)[G],
                                              float c, int tok0, int row, int len, bool partial) {
     using Tile = DecodeTile<T, D, G>;
     constexpr int NI = Tile::NI;
+#ifdef SWL_PA_PROBE_NO_MATH
+    // A/B build only (tools/gpu_attn_variants.sh): the K/V stream with next to no arithmetic — how far from the
+    // memory-only time is the kernel? Results are meaningless.
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; j += 2)
+            acc[0][j] += __builtin_bit_cast(float, vec2_t<T>{Kv[i][j], Vv[i][j + 1]});
+    return;
+#endif
     float vf[NI][8];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -132,6 +142,137 @@ __device__ __forceinline__ void attend_block(const vec8_t<T> (&qv)[G],
     }
 }
 
+// ---- matrix-core variant of attend_block (G >= 2) --------------------------------------------------------------------
+// With G query heads per kv head the VALU version above does G x (dot products + 16-lane reductions + 8-wide FMAs) per
+// 16-byte K/V fragment: measured on MI355X the arithmetic costs 22-28 % of the kernel at G = 4 (batch 32 x 1k context:
+// 32.0 us, 25.0 us with the arithmetic compiled out; G = 1: 2 % — profiles/r02f_paged_attn_nomath.md). Here the G heads
+// become the N dimension of 16 x 16 MFMA tiles (columns >= G are zero padding) and a block's 16 tokens the M / K one:
+//   S[token][head]  = K_blk . Q^T   D/32 x v_mfma_f32_16x16x32  (A = K rows from LDS, B = Q^T in registers all kernel long)
+//   O^T[d][head]   += V_blk^T . P^T D/16 x v_mfma_f32_16x16x16  (A = V^T via ds_read_b64_tr_b16, B = P^T = the S registers)
+// The K/V registers arrive in the coalesced layout of the ring (lane -> token row, 16-byte chunk); one wave-private LDS
+// tile turns them into A fragments (in-order LDS pipeline of one wave: no barrier). In the 16 x 16 C layout lane
+// (q = l/16, h = l%16) holds tokens 4q..4q+3 of head h: the scores a lane gets from QK^T are exactly the B fragment PV
+// needs from it, the online-softmax state is ONE (m, l) pair per lane, and O^T costs D/16 x 4 registers for ANY G
+// (the VALU version: 8 G). P is fed as hi + lo 16-bit halves (two MFMAs): the product keeps fp32-level accuracy
+// instead of the storage dtype's, so the numerics stay those of the VALU version (and of the reference's fp32 p,
+// paged_attn.py:74-79) at 16 more MFMA issues per block.
+typedef short short4_t __attribute__((ext_vector_type(4)));
+template <typename T>
+struct Vec4 {
+    typedef T type __attribute__((ext_vector_type(4)));
+};
+
+__device__ __forceinline__ float4_t mfma16x32(vec8_t<f16> a, vec8_t<f16> b, float4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float4_t mfma16x32(vec8_t<bf16> a, vec8_t<bf16> b, float4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float4_t mfma16x16(short4_t a, typename Vec4<f16>::type b, float4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(typename Vec4<f16>::type, a), b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float4_t mfma16x16(short4_t a, typename Vec4<bf16>::type b, float4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, __builtin_bit_cast(short4_t, b), c, 0, 0, 0);
+}
+// LDS transpose read (gfx950): the 16 lanes of a group each give the address of 4 consecutive 16-bit elements (lanes
+// 4r..4r+3 = the four quarters of row r); lane i receives column i of that 4 x 16 block: {row0[i], .., row3[i]}.
+template <typename T>
+__device__ __forceinline__ short4_t lds_tr16_b64(const T *p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3))) *)(p));
+}
+
+// All-reduce over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48), VALU only:
+// v_permlane16_swap(a, a) -> {rows 0,0,2,2 | rows 1,1,3,3}, v_permlane32_swap(b, b) -> {lo, lo | hi, hi}.
+__device__ __forceinline__ float rows_allreduce_max(float v) {
+    const auto r1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r1[0]), __uint_as_float(r1[1]));
+    const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r2[0]), __uint_as_float(r2[1]));
+}
+__device__ __forceinline__ float rows_allreduce_sum(float v) {
+    const auto r1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r1[0]) + __uint_as_float(r1[1]);
+    const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+}
+
+template <typename T, int D>
+struct MfmaTile {
+    static constexpr int KRS = D + 8;    // K row pitch (elements): 16 rows -> 16 distinct 16-byte slots for ds_read_b128
+    static constexpr int VRS = D + 16;   // V row pitch: 8 rows x 32 B tile the 64 banks exactly for the b64 transpose read
+    static constexpr int ELEMS = 16 * VRS;
+    static constexpr int QS = D / 32;    // QK^T MFMAs per block
+    static constexpr int OS = D / 16;    // PV MFMA pairs per block
+};
+
+template <typename T, int D, int G>
+__device__ __forceinline__ void attend_block_mfma(const vec8_t<T> (&qb)[MfmaTile<T, D>::QS],
+                                                  const vec8_t<T> (&Kv)[DecodeTile<T, D, G>::NI],
+                                                  const vec8_t<T> (&Vv)[DecodeTile<T, D, G>::NI], float &m, float &l,
+                                                  float4_t (&acc)[MfmaTile<T, D>::OS], T *stage, float c, int tok0,
+                                                  int row, int chunk, int lane, int len, bool partial) {
+    using Tile = DecodeTile<T, D, G>;
+    using MT = MfmaTile<T, D>;
+    constexpr int NI = Tile::NI;
+    const int q = lane >> 4, i16 = lane & 15;
+    // K: ring layout -> row-major tile -> A fragments (row = token i16, k = d)
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+        *reinterpret_cast<vec8_t<T> *>(stage + (i * Tile::TPI + row) * MT::KRS + chunk * 8) = Kv[i];
+    float4_t s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < MT::QS; ++j) {
+        const vec8_t<T> kf = *reinterpret_cast<const vec8_t<T> *>(stage + i16 * MT::KRS + 32 * j + 8 * q);
+        s = mfma16x32(kf, qb[j], s);
+    }
+    mfma_results_ready<4>(s); // the scores are read by VALU next, behind a branch (swl_common.h)
+    // V goes into the same tile once the K fragments are out (same wave: LDS executes in order)
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+        *reinterpret_cast<vec8_t<T> *>(stage + (i * Tile::TPI + row) * MT::VRS + chunk * 8) = Vv[i];
+    // s[r] = score of token tok0 + 4q + r for head i16
+    if (partial) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (tok0 + 4 * q + r >= len) s[r] = kNegBig;
+    }
+    // block maximum of head i16 over its 16 tokens = over the four lanes q = 0..3: v_permlane16_swap / v_permlane32_swap
+    // (VALU only; 1.2x cheaper than two ds_bpermute round trips through the LDS pipe this loop keeps busy)
+    float mb = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+    mb = rows_allreduce_max(mb);
+    const float m_new = fmaxf(m, mb);
+    const float alpha = fast_exp2((m - m_new) * c); // difference first (see attend_block)
+    const float mc = m_new * c;
+    float pf[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pf[r] = fast_exp2(fmaf(s[r], c, -mc));
+    if (partial) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (tok0 + 4 * q + r >= len) pf[r] = 0.f;
+    }
+    l = fmaf(l, alpha, (pf[0] + pf[1]) + (pf[2] + pf[3]));
+    m = m_new;
+    typename Vec4<T>::type ph, pl;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        ph[r] = to_t<T>(pf[r]);
+        pl[r] = to_t<T>(pf[r] - to_f(ph[r]));
+    }
+    // rescale only when some head of this wave raised its maximum (wave-uniform branch; alpha == 1 is the common case
+    // after the first blocks of a sequence)
+    if (!__all(alpha == 1.0f)) {
+#pragma unroll
+        for (int mm = 0; mm < MT::OS; ++mm) acc[mm] *= alpha;
+    }
+#pragma unroll
+    for (int mm = 0; mm < MT::OS; ++mm) {
+        const short4_t vf = lds_tr16_b64(stage + (4 * q + (i16 >> 2)) * MT::VRS + 16 * mm + 4 * (i16 & 3));
+        acc[mm] = mfma16x16(vf, ph, acc[mm]);
+        acc[mm] = mfma16x16(vf, pl, acc[mm]);
+    }
+}
+
 // Ring depth of the K/V register pipeline: a wave keeps kPaDepth 16-token blocks (K + V = 8 KiB, 32 VGPRs each)
 // resident — the one it attends plus kPaDepth-1 in flight. Little's law on this part: one CU needs ~31 GB/s
 // (8 TB/s / 256) against ~2 us of loaded HBM latency = ~64 KB in flight; 8 waves x 1 block in flight (depth 2) is
@@ -144,6 +285,9 @@ __device__ __forceinline__ void attend_block(const vec8_t<T> (&qv)[G],
 // that block is already under way — bytes in flight per CU stop being bounded by the VGPR file. 0 = off.
 #ifndef SWL_PA_L2_AHEAD
 #define SWL_PA_L2_AHEAD 0
+#endif
+#ifndef SWL_PA_MFMA_DEPTH
+#define SWL_PA_MFMA_DEPTH 2
 #endif
 
 // NW = waves per workgroup: 4 for short sequence blocks (latency-bound launches that want many
@@ -171,6 +315,13 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
     __shared__ float sm_acc[NW][G][D];
     __shared__ __attribute__((aligned(16))) T sm_q[QKV ? G * D : 8];
     __shared__ __attribute__((aligned(16))) T sm_kv[QKV ? 2 * D : 8];
+#ifdef SWL_PA_NO_MFMA
+    constexpr bool MF = false;           // A/B build: the VALU attend_block for every G
+#else
+    constexpr bool MF = G >= 2;          // matrix-core attend_block (see attend_block_mfma)
+#endif
+    using MT = MfmaTile<T, D>;
+    __shared__ __attribute__((aligned(16))) T sm_stage[MF ? NW : 1][MF ? MT::ELEMS : 8];
 
     const int split = blockIdx.x;
     const int kvh = blockIdx.y;
@@ -195,21 +346,35 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
     const int64_t layer_head = static_cast<int64_t>(p.layer) * p.KVH + kvh;
     const int64_t blk_pitch = static_cast<int64_t>(p.L) * p.KVH;
 
-    vec8_t<T> qv[G];
+    vec8_t<T> qv[MF ? 1 : G];
+    vec8_t<T> qb[MT::QS];               // MF: Q^T B fragments, lane (q, h) -> Q[head h][32 j + 8 q ..], zero for h >= G
+    const int mq = lane >> 4, mh = lane & 15;
     if constexpr (!QKV) {
-        const T *qp = static_cast<const T *>(p.q) + seq * p.q_tok_stride +
-                      static_cast<int64_t>(kvh) * G * D + chunk * 8;
+        if constexpr (MF) {
+            const T *qp = static_cast<const T *>(p.q) + seq * p.q_tok_stride +
+                          (static_cast<int64_t>(kvh) * G + min(mh, G - 1)) * D + 8 * mq;
 #pragma unroll
-        for (int g = 0; g < G; ++g) qv[g] = load8(qp + g * D);
+            for (int j = 0; j < MT::QS; ++j) {
+                qb[j] = load8(qp + 32 * j);
+                if (mh >= G) qb[j] = vec8_t<T>{};
+            }
+        } else {
+            const T *qp = static_cast<const T *>(p.q) + seq * p.q_tok_stride +
+                          static_cast<int64_t>(kvh) * G * D + chunk * 8;
+#pragma unroll
+            for (int g = 0; g < G; ++g) qv[g] = load8(qp + g * D);
+        }
     }
     const int pos = len - 1;          // the token being decoded
     const int last_blk = pos / kBlk;
 
-    float m[G], l[G], acc[G][8];
+    float m[MF ? 1 : G], l[MF ? 1 : G], acc[MF ? 1 : G][8];
+    float4_t acc4[MT::OS];              // MF: O^T[d = 16 mm + 4 q + r][head h]
 
     // ring slots: what the 256-VGPR budget of a 2-waves-per-SIMD kernel holds without spilling (accumulators grow
     // with G): G = 1 -> 4, G = 2 -> 3, G >= 4 -> 2
-    constexpr int ND = SWL_PA_DEPTH > 0 ? (G >= 8 ? 2 : SWL_PA_DEPTH) : (G == 1 ? 4 : (G == 2 ? 3 : 2));
+    // (the matrix-core path keeps D/16 x 4 accumulator registers whatever G is: 3 slots for every G >= 2)
+    constexpr int ND = SWL_PA_DEPTH > 0 ? ((G >= 8 && !MF) ? 2 : SWL_PA_DEPTH) : (G == 1 ? 4 : (MF ? SWL_PA_MFMA_DEPTH : (G == 2 ? 3 : 2)));
     vec8_t<T> Kr[ND][NI], Vr[ND][NI];
     auto load_phys = [&](int64_t phys, vec8_t<T>(&Kd)[NI], vec8_t<T>(&Vd)[NI]) {
         const int64_t base = (phys * blk_pitch + layer_head) * tile_elems + lane * 8;
@@ -224,7 +389,11 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
     };
     auto attend = [&](int b, vec8_t<T>(&Kd)[NI], vec8_t<T>(&Vd)[NI]) {
         const int tok0 = b * kBlk;
-        attend_block<T, D, G>(qv, Kd, Vd, m, l, acc, c, tok0, row, len, tok0 + kBlk > len);
+        if constexpr (MF)
+            attend_block_mfma<T, D, G>(qb, Kd, Vd, m[0], l[0], acc4, &sm_stage[wave][0], c, tok0, row, chunk, lane, len,
+                                       tok0 + kBlk > len);
+        else
+            attend_block<T, D, G>(qv, Kd, Vd, m, l, acc, c, tok0, row, len, tok0 + kBlk > len);
     };
     // Drain steps only (a wave's last block is always attended there): in the QKV variant the block that holds the
     // token being decoded takes that token's k/v from the prologue's LDS copy — its pool read raced with the store.
@@ -384,16 +553,26 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
         __builtin_amdgcn_sched_barrier(0);  // do not hoist the next requests above the slab sums (register pressure)
         prefetch_kv(b, IntTag<NDP>{}, IntTag<ND>{}); // the remaining slots: the slab registers are free again
         __syncthreads();
+        if constexpr (MF) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) qv[g] = *reinterpret_cast<const vec8_t<T> *>(&sm_q[g * D + chunk * 8]);
+            for (int j = 0; j < MT::QS; ++j) {
+                qb[j] = *reinterpret_cast<const vec8_t<T> *>(&sm_q[min(mh, G - 1) * D + 32 * j + 8 * mq]);
+                if (mh >= G) qb[j] = vec8_t<T>{};
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; ++g) qv[g] = *reinterpret_cast<const vec8_t<T> *>(&sm_q[g * D + chunk * 8]);
+        }
     }
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
+    for (int g = 0; g < (MF ? 1 : G); ++g) {
         m[g] = kNegBig;
         l[g] = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
     }
+#pragma unroll
+    for (int mm = 0; mm < MT::OS; ++mm) acc4[mm] = float4_t{0.f, 0.f, 0.f, 0.f};
     // steady state: every refill is unconditional, so the waits between slots are exact counted vmcnt waits (a
     // conditional load in the body makes the compiler wait for one slot more than needed); slot d attends block
     // b + d*NW and is refilled with block b + (d+ND)*NW
@@ -441,6 +620,24 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
         if (b + (d + ND) * NW < blk_end) attend_tail(b + (d + ND) * NW, Kr[d], Vr[d]);
     if constexpr (SWL_PA_L2_AHEAD > 0) asm volatile("" ::"v"(pf)); // the pinned register lives to here
 
+    if constexpr (MF) {
+        // O^T of the last block is stored by DS instructions below (swl_common.h)
+#pragma unroll
+        for (int mm = 0; mm < MT::OS; ++mm) mfma_results_tie(acc4[mm]);
+        mfma_results_ready<4>(acc4[MT::OS - 1]);
+        // the four lanes (q = 0..3) of a head share m and each hold the row sum of their own tokens; O^T is complete
+        const float lt = rows_allreduce_sum(l[0]);
+        if (mh < G) {
+            if (mq == 0) {
+                sm_ml[wave][mh][0] = m[0];
+                sm_ml[wave][mh][1] = lt;
+            }
+#pragma unroll
+            for (int mm = 0; mm < MT::OS; ++mm)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sm_acc[wave][mh][16 * mm + 4 * mq + r] = acc4[mm][r];
+        }
+    } else {
     // ---- merge the TPI rows of this wave (each row holds tokens == row mod TPI) ----------------
 #pragma unroll
     for (int mask = LPT; mask < 64; mask <<= 1) {
@@ -471,6 +668,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
             for (int j = 0; j < 8; ++j) sm_acc[wave][g][chunk * 8 + j] = acc[g][j];
         }
     }
+    } // !MF
     __syncthreads();
 
     // ---- merge the NW waves and write the partial (or the final output when there is one split) -
@@ -571,8 +769,8 @@ template <typename T, int D, int G, bool QKV>
 static int launch_phase1(const PagedAttnParams &p, int Bd, hipStream_t stream) {
     const dim3 grid(p.num_seq_blocks, p.KVH, Bd);
     // >= 32 KV blocks per sequence block: 8-wave workgroups (>= 4 blocks per wave); else 4 waves.
-    // (G = 8 needs > 256 registers per lane: it stays on 4-wave workgroups, one wave per SIMD.)
-    if (G <= 4 && p.seq_block_size >= 32 * kBlk)
+    // (the VALU variant of G = 8 would need > 256 registers per lane; the matrix-core one, G >= 2, does not.)
+    if (p.seq_block_size >= 32 * kBlk)
         hipLaunchKernelGGL((paged_attn_phase1_kernel<T, D, G, 8, QKV>), grid, dim3(512), 0, stream, p, p.block_table,
                            p.seq_lens, p.seq_ids);
     else

@@ -185,6 +185,9 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(PrefillParams p) {
             }
         }
         __builtin_amdgcn_s_setprio(0);
+        // S^T is read by VALU next, behind the diagonal-tile branch (swl_common.h)
+        mfma_results_tie(st[0]);
+        mfma_results_ready<8>(st[1]);
         // causal mask on the diagonal tiles (keys beyond len are > every valid q row as well)
         if (key0 + kBK - 1 > q0w) {
 #pragma unroll
@@ -251,6 +254,9 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(PrefillParams p) {
     }
 
     // ---- epilogue: O[qrow][d] = O^T[d][qrow] / l ---------------------------------------------------
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) mfma_results_tie(ot[dt]);
+    mfma_results_ready<8>(ot[DT - 1]);
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     if (qrow < len) {

@@ -239,6 +239,27 @@ __device__ __forceinline__ void rotate8(vec8_t<T> &x0, vec8_t<T> &x1, const vec8
     }
 }
 
+// Wait states between an MFMA and the first NON-MFMA instruction that reads its result. The matrix pipe writes its
+// destination registers some passes after issue; the padding a VALU / DS / VMEM reader needs is software's job (CDNA3/4
+// ISA, "manually inserted wait states"). hipcc's hazard recognizer inserts it along fall-through code but, on ROCm 7.2
+// for gfx950, NOT on the taken side of a branch that sits between the MFMA and the reader: seen in paged_attn.hip (r02),
+// where the uniform `if (partial)` left `v_mfma ... ; s_cbranch ; v_max_f32 <result>` on the common path and the block
+// maximum came out different from run to run (profiles/r02g_paged_attn_mfma.md). The softmax stayed self-consistent
+// (any reference maximum is a valid one), so every parity test passed; only the last bit of some outputs moved.
+// mfma_results_ready(acc) is tied to the accumulator as an in/out operand, so no compiler pass can move the MFMAs
+// below it or the readers above it (a free-standing `asm volatile("s_nop")` between sched_barriers WAS moved above
+// the MFMA chain). Several accumulators: mfma_results_tie() each, then mfma_results_ready() on the last one written.
+// PASSES (4 cycles each): 4 for 16x16x32 / 16x16x16, 8 for 32x32x16 — the wait is passes + 3, rounded up generously.
+template <typename V>
+__device__ __forceinline__ void mfma_results_tie(V &acc) {
+    asm volatile("" : "+v"(acc));
+}
+template <int PASSES, typename V>
+__device__ __forceinline__ void mfma_results_ready(V &acc) {
+    if constexpr (PASSES <= 4) asm volatile("s_nop 9" : "+v"(acc));            // 10 wait states
+    else asm volatile("s_nop 15" : "+v"(acc));                                 // 16 wait states
+}
+
 // exp2 on the hardware transcendental unit (v_exp_f32 IS 2^x).
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }

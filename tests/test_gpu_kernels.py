@@ -280,6 +280,31 @@ def test_paged_attention_vs_oracle(dtype, sbs, H, KVH, D):
     assert err <= tol, err
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sbs", [64, 1024])
+@pytest.mark.parametrize("H,KVH,D", [(32, 8, 128), (8, 4, 64), (16, 2, 64), (32, 32, 128)])
+def test_paged_attention_is_run_to_run_deterministic(dtype, sbs, H, KVH, D):
+    """The same launch on the same inputs must give the same bits every time, 8-wave and 4-wave workgroups, sequences
+    spread over one / some / all waves of a workgroup. (r02: the matrix-core kernel with its block maximum taken
+    through ds_bpermute returned a different — self-consistent — running maximum from run to run in the 8-wave
+    variant; outputs then differed in their last bit. The cross-lane step is VALU-only now.)"""
+    g = gen(H * 17 + D + sbs)
+    lens = [1, 15, 16, 17, 63, 64, 65, 300, 129, 1000]
+    L, layer = 2, 1
+    q, kc, vc, bt, seq_ids = _paged_case(g, H, KVH, D, L, lens, dtype, layer)
+    mc, ec = NS(num_q_heads=H, num_kv_heads=KVH, head_dim=D, num_layers=L), NS(block_size=16)
+    qd, kd, vd, btd = q.cuda(), kc.cuda(), vc.cuda(), bt.cuda()
+    st = _paged_state(lens, seq_ids, sbs, D, "cuda")
+    outs = []
+    for _ in range(12):
+        o = torch.zeros_like(qd)
+        K().paged_attention(qd, kd, vd, btd, mc, ec, st, layer, o)
+        outs.append(o)
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
 def test_paged_attention_split_invariance_and_properties():
     """Size-independent properties at Llama-3-8B head geometry and long contexts: the result must
     not depend on the split-K width (up to fp32 reassociation), must be linear in V, and must be

@@ -349,3 +349,26 @@ def test_engine_config_rejects_unsupported_block_size():
         EngineConfig(block_size=32, **base)
     with pytest.raises(ValueError, match="dtype"):
         EngineConfig(block_size=16, dtype="float32", **base)
+
+
+def test_graph_bucket_keeps_splits_balanced_and_few():
+    """hipGraph replay quantises the flash-decoding split width so that a growing batch reuses its captured graph; the
+    quantised width must stay within a few percent of the planner's (balanced splits: the longest one sets the kernel
+    time), cover the longest sequence with the captured split count, and take few distinct values per octave."""
+    import types
+    from swiftllm_amd.worker.model import LlamaModel
+    from swiftllm_amd.worker.batch_plan import select_seq_block_size
+    widths = set()
+    for batch, kvh, n0 in ((4, 32, 16372), (32, 8, 1024), (1, 8, 1024), (8, 8, 40000), (2, 32, 131000)):
+        for step in range(0, 600, 7):
+            lens = [n0 + step] * batch
+            sbs = select_seq_block_size(lens, kvh, 256)
+            plan = types.SimpleNamespace(seq_block_size=sbs, num_seq_blocks=-(-max(lens) // sbs), max_decoding_len=max(lens))
+            q, cap = LlamaModel._graph_bucket(None, plan)
+            widths.add((batch, kvh, n0, q, cap))
+            assert cap * q >= max(lens) + 1
+            if plan.num_seq_blocks > 1:
+                assert sbs <= q <= sbs * 1.07 + 64, (lens[0], sbs, q)
+                # the longest split of the replayed geometry is within 7 % of the planner's
+                assert q <= 1.07 * sbs + 64
+    assert len(widths) <= 5 * 4, len(widths)

@@ -383,6 +383,29 @@ int swl_gemm_wgk_add_scale(void *x_scaled, void *residual, float *ssq_out, const
                            const void *w_packed, int32_t M, int32_t N, int32_t K, int64_t x_row_stride, int32_t dtype,
                            swl_stream_t stream);
 
+/* ---- decode projections for very small batches that consume the previous projection's slabs (csrc/gemm_tiny.hip) ----
+ * M <= swl_gemm_tiny_max_tokens() (4). At batch 1 the two split-K consumers of a decode layer (swl_splitk_add_scale:
+ * reference rmsnorm.py:67-89 at transformer_layer.py:46,120) are 10 % of the layer and run on four workgroups; here the
+ * NEXT projection rebuilds its activations itself while its first weight tiles are in flight — residual_out = round(sum
+ * slabs_in) + residual_in (stored by the workgroups with blockIdx.x == 0; residual_out != residual_in, the others still
+ * read the old rows), x = round(residual_out * norm_w) kept in LDS for the whole K loop — and carries the sums of squares
+ * to where the deferred 1/rms is applied. Packed weights (swl_gemm_pack_weight), K % 128 == 0, K / k_splits_out <= 4096.
+ *   swl_gemm_tiny_partial_from_splitk: the fused qkv projection (transformer_layer.py:46-56): slabs_out[k_splits_out][M][N]
+ *     fp32 = x . W^T per K-chunk (the bits of swl_splitk_add_scale + swl_gemm_skinny_packed_partial), ssq_out[k_splits_out]
+ *     [M] = sums of squares of the residual rows per K-chunk — what swl_paged_attn_decode_qkv_rs takes as row_ssq
+ *     (ssq_parts = k_splits_out). slabs_out != slabs_in.
+ *   swl_gemm_tiny_silu_gate_from_splitk: the FFN up/gate projection + SiLU-gate (transformer_layer.py:120-127):
+ *     out[M, I] = up * silu(gate) of rstd[m] * (x . [up ; gate]^T), rstd from the same rows. I % 64 == 0, K <= 4096. */
+int swl_gemm_tiny_max_tokens(void);
+int swl_gemm_tiny_partial_from_splitk(float *slabs_out, size_t slabs_out_bytes, int32_t k_splits_out, float *ssq_out,
+                                      const float *slabs_in, int32_t k_splits_in, const void *residual_in,
+                                      void *residual_out, const void *norm_w, const void *w_packed, int32_t M, int32_t N,
+                                      int32_t K, int32_t dtype, swl_stream_t stream);
+int swl_gemm_tiny_silu_gate_from_splitk(void *out, const float *slabs_in, int32_t k_splits_in, const void *residual_in,
+                                        void *residual_out, const void *norm_w, float eps, const void *w_up_gate_packed,
+                                        int32_t M, int32_t I, int32_t K, int64_t out_row_stride, int32_t dtype,
+                                        swl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,6 +80,8 @@ SIGNATURES = {
                                           _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _P],
     "swl_gemm_wgk": [_P, _I32, _P, _P, _P, _I32, _I32, _F32, _I32, _I32, _I32, _I64, _I64, _I32, _P],
     "swl_gemm_wgk_add_scale": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I64, _I32, _P],
+    "swl_gemm_tiny_partial_from_splitk": [_P, ctypes.c_size_t, _I32, _P, _P, _I32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
+    "swl_gemm_tiny_silu_gate_from_splitk": [_P, _P, _I32, _P, _P, _P, _F32, _P, _I32, _I32, _I32, _I64, _I32, _P],
 }
 # Entry points that do not follow the "int rc = f(...)" convention.
 _SPECIAL = {
@@ -91,6 +93,7 @@ _SPECIAL = {
     "swl_gemm_skinny_choose_splits": ([_I32, _I32], _I32),
     "swl_gemm_packed_mid_choose_splits": ([_I32, _I32, _I32], _I32),
     "swl_gemm_wgk_supported": ([_I32, _I32, _I32], _I32),
+    "swl_gemm_tiny_max_tokens": ([], _I32),
 }
 
 _lock = threading.Lock()

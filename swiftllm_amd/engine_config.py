@@ -61,6 +61,9 @@ class EngineConfig:
     # that fill the chip instead of one workgroup per token. Moves one rounding (the un-normalised
     # activations are rounded, the scale is applied in fp32); needs hidden % 1024 == 0, else the exact path runs.
     defer_rmsnorm: bool = True
+    # Decode batches of <= 4 sequences: the qkv and up/gate projections sum the previous projection's split-K slabs
+    # themselves (csrc/gemm_tiny.hip) — 5 launches per layer instead of 7. Needs defer_rmsnorm, packed weights, hidden <= 4096.
+    tiny_decode_batches: bool = True
     # Allocate the host swap pool in pinned memory (true async DMA for swap_blocks).
     pin_swap_memory: bool = True
 

@@ -202,6 +202,82 @@ def linear_silu_gate(a: torch.Tensor, w_up_gate: torch.Tensor, row_scale=None):
     return out
 
 
+# ---- very small decode batches: the projection sums the previous projection's slabs itself (csrc/gemm_tiny.hip) ------
+_TINY_MAX_M = 4             # swl_gemm_tiny_max_tokens(): what the kernels accept
+_TINY_POLICY_M = 2          # what the layer uses them for: each workgroup re-reads 8 slabs x M x K-chunk through its L1
+                            # (55 GB/s per CU): measured on MI355X, batch 1 gains 2-3 %, batch 2 is even, batch 4 loses 3 %
+_TINY_MAX_KC = 4096         # K-chunk a workgroup keeps resident in LDS
+_alt_workspaces = {}        # device -> second split-K scratch: a projection cannot write the slabs it is reading
+_alt_residuals = {}         # (device, shape, dtype) -> second residual buffer (same reason; fixed address for hipGraphs)
+
+
+def _alt_workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    ws = _alt_workspaces.get(device)
+    if ws is None or ws.numel() * 4 < nbytes:
+        if ws is not None:
+            _retired.append(ws)
+        ws = torch.empty(max(nbytes, 4 << 20) // 4, dtype=torch.float32, device=device)
+        _alt_workspaces[device] = ws
+    return ws
+
+
+def alt_residual_like(residual: torch.Tensor) -> torch.Tensor:
+    key = (residual.device, tuple(residual.shape), residual.dtype)
+    buf = _alt_residuals.get(key)
+    if buf is None:
+        buf = _alt_residuals[key] = torch.empty_like(residual)
+    return buf
+
+
+def tiny_from_splitk_ok(partials, w: torch.Tensor, silu: bool = False) -> bool:
+    """Can `w`'s projection consume `partials` (the previous projection's slabs) itself? <= 4 tokens, packed weight,
+    the K-chunk of a workgroup fits LDS."""
+    if not isinstance(partials, SplitKPartials) or _packed_of(w) is None:
+        return False
+    m, k = partials.shape
+    n = w.shape[0]
+    if not (0 < m <= _TINY_MAX_M and w.shape[1] == k and k % 128 == 0 and w.dtype == partials.dtype):
+        return False
+    if silu:
+        return k <= _TINY_MAX_KC and n % 128 == 0
+    ks = _hip.load().swl_gemm_skinny_choose_splits(n, k)
+    return n % 32 == 0 and ks in (1, 2, 4) and k % ks == 0 and (k // ks) % 128 == 0 and k // ks <= _TINY_MAX_KC
+
+
+def linear_splitk_from_splitk(partials, residual_in: torch.Tensor, residual_out: torch.Tensor, norm_w: torch.Tensor,
+                              w: torch.Tensor):
+    """residual_out = round(sum of `partials`) + residual_in; x = round(residual_out * norm_w) (never materialised);
+    returns (SplitKPartials of x @ w^T, ssq[k_splits, M]) — the slabs and the per-K-chunk sums of squares the slab-fed
+    attention kernel takes (paged_attention_from_qkv_splitk with a RowScalePending). One launch instead of
+    add_scale_from_splitk + linear_splitk."""
+    assert tiny_from_splitk_ok(partials, w) and residual_in.data_ptr() != residual_out.data_ptr()
+    m, k = partials.shape
+    n = w.shape[0]
+    ks = _hip.load().swl_gemm_skinny_choose_splits(n, k)
+    ws = _alt_workspace(residual_in.device, ks * m * n * 4)
+    assert ws.data_ptr() != partials.slabs.data_ptr()
+    ssq = torch.empty((ks, m), dtype=torch.float32, device=residual_in.device)
+    _hip.call("swl_gemm_tiny_partial_from_splitk", _hip.ptr(ws), ws.numel() * 4, ks, _hip.ptr(ssq), _hip.ptr(partials.slabs),
+              partials.k_splits, _hip.ptr(residual_in), _hip.ptr(residual_out), _hip.ptr(norm_w), _hip.ptr(_packed_of(w)),
+              m, n, k, _hip.dtype_code(partials.dtype), _hip.stream())
+    return SplitKPartials(ws, ks, m, n, partials.dtype), ssq
+
+
+def linear_silu_gate_from_splitk(partials, residual_in: torch.Tensor, residual_out: torch.Tensor, norm_w: torch.Tensor,
+                                 eps: float, w_up_gate: torch.Tensor) -> torch.Tensor:
+    """residual_out = round(sum of `partials`) + residual_in; returns silu_and_mul(rmsnorm(residual_out) @ up_gate^T)
+    [M, I] with the 1/rms applied in fp32 in the epilogue (deferred normalisation). One launch instead of
+    add_scale_from_splitk + linear_silu_gate."""
+    assert tiny_from_splitk_ok(partials, w_up_gate, silu=True) and residual_in.data_ptr() != residual_out.data_ptr()
+    m, k = partials.shape
+    inter = w_up_gate.shape[0] // 2
+    out = torch.empty((m, inter), dtype=partials.dtype, device=residual_in.device)
+    _hip.call("swl_gemm_tiny_silu_gate_from_splitk", _hip.ptr(out), _hip.ptr(partials.slabs), partials.k_splits,
+              _hip.ptr(residual_in), _hip.ptr(residual_out), _hip.ptr(norm_w), eps, _hip.ptr(_packed_of(w_up_gate)), m,
+              inter, k, inter, _hip.dtype_code(partials.dtype), _hip.stream())
+    return out
+
+
 # ---- fused decode layer (csrc/gemm_skinny.hip: "decode-layer fusion hooks") --------------------------------
 _MAX_NORM_K = 4096          # kMaxNormK: the normalising prologue keeps the norm weight of a K-chunk in LDS
 _fused_state = {}           # device -> (tile counters int64[4096], ssq fp32[1024 * 32]); fixed addresses

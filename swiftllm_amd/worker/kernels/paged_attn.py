@@ -70,7 +70,7 @@ def paged_attention_from_qkv_splitk(partials, k_cache: torch.Tensor, v_cache: to
         # the prologue applies 1/rms to the fp32 slab sums before rounding them
         assert partials.k_splits in (1, 2, 4) and row_scale.ssq.shape == (row_scale.parts, nd)
         _hip.call("swl_paged_attn_decode_qkv_rs", _hip.ptr(o), _hip.ptr(partials.slabs), partials.k_splits,
-                  _hip.ptr(row_scale.ssq), row_scale.parts, row_scale.x.shape[1], row_scale.eps,
+                  _hip.ptr(row_scale.ssq), row_scale.parts, row_scale.hidden, row_scale.eps,
                   _hip.ptr(infer_state.position_cos), _hip.ptr(infer_state.position_sin),
                   _hip.ptr(infer_state.position_indices), _hip.ptr(k_cache), _hip.ptr(v_cache), _hip.ptr(block_table),
                   _hip.ptr(infer_state.seq_ids), _hip.ptr(infer_state.decoding_seq_lens), _hip.ptr(scratch),

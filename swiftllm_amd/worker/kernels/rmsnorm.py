@@ -56,10 +56,13 @@ class RowScalePending:
     """Activations whose RMSNorm scale is still pending: `x` = round(residual * norm_weight) [tokens, hidden], `ssq`
     [parts, tokens] the per-1024-column sums of squares of the residual rows. The consumer projection multiplies its
     fp32 results by 1/sqrt(sum(ssq)/hidden + eps) before rounding (linear_silu_gate / paged_attention_from_qkv_splitk)."""
-    __slots__ = ("x", "ssq", "parts", "eps")
+    __slots__ = ("x", "ssq", "parts", "eps", "hidden")
 
-    def __init__(self, x: torch.Tensor, ssq: torch.Tensor, parts: int, eps: float):
+    def __init__(self, x, ssq: torch.Tensor, parts: int, eps: float, hidden: int = 0):
+        # x is None when the consumer of the pending scale never sees the scaled activations as a tensor
+        # (kernels/linear.py: linear_splitk_from_splitk keeps them in LDS); `hidden` = their row length
         self.x, self.ssq, self.parts, self.eps = x, ssq, parts, eps
+        self.hidden = hidden or (x.shape[1] if x is not None else 0)
 
 
 def deferred_norm_ok(num_tokens: int, hidden: int) -> bool:

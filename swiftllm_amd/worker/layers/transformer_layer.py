@@ -18,6 +18,11 @@ the o_proj / down_proj slabs only do the element-wise part, in a launch that fil
 the per-token 1/rms is applied by the consumer of the normalised activations — the slab-fed attention prologue for the
 qkv projection, the SiLU-gate GEMM's epilogue for the FFN — in fp32, before its one rounding.
 
+Very small decode batches (tiny_decode_batches, <= 4 sequences): the two consumers above disappear altogether — the
+qkv projection and the up/gate projection sum the previous projection's slabs themselves while their first weight
+tiles are in flight (kernels/linear.py: linear_splitk_from_splitk / linear_silu_gate_from_splitk, csrc/gemm_tiny.hip),
+the residual stream ping-pongs between two buffers: 5 launches per layer instead of 7.
+
 Fused decode layer (fuse_decode_layer, batches of <= 32 sequences): the hand-offs themselves move into the
 GEMMs — qkv projection (+ attention norm on the fly) with rotary/KV-store in its epilogue, attention,
 o_proj with the residual add in its epilogue, up/gate (+ FFN norm on the fly) with SiLU-gate, down_proj with
@@ -28,7 +33,10 @@ import torch
 
 from ..kernels.linear import (NormPending, SplitKPartials, fused_layer_ok, linear, linear_add_residual,
                               linear_norm_silu_gate, linear_qkv_rope_store, linear_silu_gate, linear_splitk)
-from ..kernels.linear import row_scaled_silu_gate_ok
+from ..kernels.linear import _TINY_POLICY_M as TINY_POLICY_M
+from ..kernels.linear import (row_scaled_silu_gate_ok, alt_residual_like, linear_silu_gate_from_splitk,
+                              linear_splitk_from_splitk, tiny_from_splitk_ok)
+from ..kernels.rmsnorm import RowScalePending
 from ..kernels.rmsnorm import (add_scale_from_splitk, deferred_norm_ok, fused_add_rmsnorm_inplace,
                                fused_add_rmsnorm_from_splitk, rmsnorm_inplace)
 from ..kernels.rotary_emb import (rotary_embedding_inplace, rotary_embedding_and_store_kvcache_decode,
@@ -48,6 +56,7 @@ class LlamaTransformerLayer:
         self.layer_id = layer_id
         self.skinny = bool(getattr(engine_config, "use_skinny_gemm", False))
         self._qkv_splits = None     # k-splits the skinny GEMM picks for the fused qkv projection (cached)
+        self._tiny_ok = None        # can this layer run the <= 4-token path (cached)
 
     def _split_qkv(self, qkv: torch.Tensor):
         cfg = self.model_config
@@ -79,6 +88,8 @@ class LlamaTransformerLayer:
         # residual_buf <- input_embds + residual_buf ; input_embds <- rmsnorm(residual_buf)
         row_scale = None
         if isinstance(input_embds, SplitKPartials):     # the previous layer's down projection, unreduced
+            if self._tiny_decode_applies(st, input_embds, residual_buf):
+                return self._forward_decode_tiny(input_embds, residual_buf, k_cache, v_cache, block_table, st)
             if self._deferred_attn_norm_ok(st):
                 row_scale = add_scale_from_splitk(input_embds, residual_buf, w.attn_norm, cfg.rms_norm_eps)
                 input_embds = row_scale.x
@@ -107,6 +118,38 @@ class LlamaTransformerLayer:
             from swiftllm_amd import _hip
             self._qkv_splits = int(_hip.load().swl_gemm_skinny_choose_splits(w.qkv_proj.shape[0], w.qkv_proj.shape[1]))
         return self._qkv_splits in (1, 2, 4)
+
+    def _tiny_decode_applies(self, st, partials, residual_buf) -> bool:
+        """<= 4 decoding sequences on the deferred-norm fast path, every projection of the layer split over K (so the
+        NEXT layer receives slabs again) and the two consuming projections able to rebuild their input themselves."""
+        cfg, ecfg, w = self.model_config, self.engine_config, self.weight
+        if not (getattr(ecfg, "tiny_decode_batches", True) and partials.shape[0] <= TINY_POLICY_M
+                and self._deferred_attn_norm_ok(st)
+                and residual_buf.is_contiguous() and tiny_from_splitk_ok(partials, w.qkv_proj)):
+            return False
+        if self._tiny_ok is None:
+            from swiftllm_amd import _hip
+            splits = _hip.load().swl_gemm_skinny_choose_splits
+            self._tiny_ok = bool(w.up_gate_proj.shape[0] % 128 == 0 and w.up_gate_proj.shape[1] <= 4096
+                                 and getattr(w.up_gate_proj, "_swl_packed", None) is not None
+                                 and splits(w.o_proj.shape[0], w.o_proj.shape[1]) > 1
+                                 and splits(w.down_proj.shape[0], w.down_proj.shape[1]) > 1)
+        return self._tiny_ok
+
+    def _forward_decode_tiny(self, partials, residual_buf, k_cache, v_cache, block_table, st):
+        cfg, ecfg, w = self.model_config, self.engine_config, self.weight
+        eps = cfg.rms_norm_eps
+        alt = alt_residual_like(residual_buf)
+        # residual_buf + down slabs -> alt ; qkv slabs of round(alt * attn_norm), 1/rms pending
+        qkv, ssq = linear_splitk_from_splitk(partials, residual_buf, alt, w.attn_norm, w.qkv_proj)
+        o = torch.empty_like(residual_buf)
+        paged_attention_from_qkv_splitk(qkv, k_cache, v_cache, block_table, cfg, ecfg, st, self.layer_id, o,
+                                        row_scale=RowScalePending(None, ssq, qkv.k_splits, eps, cfg.hidden_size))
+        attn_out = linear_splitk(o, w.o_proj)
+        assert isinstance(attn_out, SplitKPartials)
+        # alt + o_proj slabs -> residual_buf ; up * silu(gate) of rmsnorm(residual_buf)
+        act = linear_silu_gate_from_splitk(attn_out, alt, residual_buf, w.ffn_norm, eps, w.up_gate_proj)
+        return linear_splitk(act, w.down_proj)
 
     def _fused_decode_applies(self, st, residual_buf) -> bool:
         cfg, ecfg, w = self.model_config, self.engine_config, self.weight

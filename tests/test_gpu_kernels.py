@@ -994,3 +994,53 @@ def test_deferred_rmsnorm_attention_matches_exact_path(dtype, sbs):
     assert dk <= 4 * eps * kmax and dv <= 4 * eps * kmax
     assert do <= 4 * eps * max(1.0, o1.float().abs().max().item())
     assert not torch.equal(kc2.cpu(), kc)
+
+
+# ---- very small decode batches: the projection consumes the previous projection's slabs itself (gemm_tiny.hip) ----
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
+@pytest.mark.parametrize("hid,N,inter", [(4096, 6144, 14336), (512, 768, 1024), (1024, 256, 384)])
+def test_tiny_batch_projections_equal_consumer_plus_gemm(dtype, M, hid, N, inter):
+    """linear_splitk_from_splitk / linear_silu_gate_from_splitk (one launch each) against the two-launch paths they replace:
+    add_scale_from_splitk + linear_splitk, add_scale_from_splitk + linear_silu_gate(row_scale). Residual and qkv slabs
+    bit for bit (same slab order, same MFMA order); the sums of squares are grouped by K-chunk instead of by 1024
+    columns, so they — and the SiLU-gate output through its 1/rms — may differ by fp32 summation order: a last-bit
+    difference in rstd can flip the rounding of the up and of the gate projection (one ulp each), silu and the product
+    carry them on: <= 4 ulp of the storage dtype on the output."""
+    import importlib
+    L = importlib.import_module("swiftllm_amd.worker.kernels.linear")
+    R = importlib.import_module("swiftllm_amd.worker.kernels.rmsnorm")
+    g = gen(M * 7 + hid + N)
+    eps = 1e-5
+    wq = (torch.randn(N, hid, generator=g) * hid ** -0.5).to(dtype).cuda()
+    wug = (torch.randn(2 * inter, hid, generator=g) * hid ** -0.5).to(dtype).cuda()
+    L.pack_weight(wq); L.pack_weight(wug)
+    norm_w = (1 + 0.1 * torch.randn(hid, generator=g)).to(dtype).cuda()
+    res0 = torch.randn(M, hid, generator=g).to(dtype).cuda()
+    ks_in = 8
+    slabs = (torch.randn(ks_in, M, hid, generator=g) * 0.3).float().cuda().contiguous()
+    part = L.SplitKPartials(slabs.view(-1), ks_in, M, hid, dtype)
+    if not L.tiny_from_splitk_ok(part, wq):
+        pytest.skip("shape outside the tiny-batch kernel's limits")
+    # two-launch reference
+    r_ref = res0.clone()
+    pend = R.add_scale_from_splitk(part, r_ref, norm_w, eps) if R.deferred_norm_ok(M, hid) else None
+    if pend is None:
+        pytest.skip("deferred norm needs hidden % 1024 == 0 for the two-launch twin")
+    q_ref = L.linear_splitk(pend.x, wq, always=True)
+    q_ref_sum = q_ref.slabs[: q_ref.k_splits * M * N].view(q_ref.k_splits, M, N).clone()
+    act_ref = L.linear_silu_gate(pend.x, wug, row_scale=pend)
+    # one launch each
+    r_new = torch.empty_like(res0)
+    q_new, ssq = L.linear_splitk_from_splitk(part, res0, r_new, norm_w, wq)
+    assert q_new.k_splits == q_ref.k_splits
+    assert torch.equal(r_new, r_ref)
+    assert torch.equal(q_new.slabs[: q_new.k_splits * M * N].view(q_new.k_splits, M, N), q_ref_sum)
+    tot_ref, tot_new = pend.ssq.sum(0), ssq.sum(0)
+    assert ((tot_ref - tot_new).abs() <= 2e-6 * tot_ref).all()
+    r_new2 = torch.empty_like(res0)
+    act_new = L.linear_silu_gate_from_splitk(part, res0, r_new2, norm_w, eps, wug)
+    assert torch.equal(r_new2, r_ref)
+    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    err = (act_new.float() - act_ref.float()).abs()
+    assert (err <= 4 * ulp * act_ref.float().abs() + 1e-5).all(), err.max().item()

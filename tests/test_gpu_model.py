@@ -330,3 +330,54 @@ def test_full_width_layers_fast_path_equals_reference_op_sequence(tmp_path, dtyp
     # (no bit-equality between "default" and "hipgraph": since r02 graph mode rounds seq_block_size up to a power of
     # two to bound the graph cache (model.py:_decode_graph), so the attention splits — and with them the fp32
     # summation order — differ from the eager plan's; both are held to the reference run above.)
+
+
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+@pytest.mark.parametrize("batch", [1, 2])
+def test_tiny_batch_decode_path_equals_the_consumer_path(tmp_path, dtype, batch):
+    """EngineConfig.tiny_decode_batches at Llama-3-8B layer geometry (2 layers): the <= 4-sequence path (projections that
+    sum the previous projection's slabs themselves, residual ping-pong) against the same engine with it switched off —
+    same greedy tokens over 8 decode steps with and without hipGraph replay, logits within the storage dtype's rounding
+    (the only arithmetic difference is the fp32 summation order of the sums of squares)."""
+    cfg = synth.make_config(num_hidden_layers=2, hidden_size=4096, num_attention_heads=32, num_key_value_heads=8,
+                            intermediate_size=14336, vocab_size=4096, max_position_embeddings=2048, rope_theta=500000.0)
+    tdtype = torch.float16 if dtype == "float16" else torch.bfloat16
+    sd = synth.make_state_dict(cfg, seed=17, dtype=tdtype)
+    g = torch.Generator().manual_seed(4)
+    lens = [300, 17, 1, 64][:batch]
+    prompts = [torch.randint(0, cfg["vocab_size"], (n,), generator=g).tolist() for n in lens]
+    base = dict(max_blocks_per_seq=32, max_tokens_in_batch=512, max_batch_size=4, max_seqs_in_block_table=8, dtype=dtype)
+    synth.write_model_dir(str(tmp_path), cfg, sd)
+    del sd
+    from swiftllm_amd import LlamaModel
+
+    def run(opts, forced=None):
+        model = LlamaModel(_engine_config(str(tmp_path), **base, **opts))
+        model.load_weights()
+        model.init_kvcache_and_swap(64)
+        model.post_layer.logits_tap = []
+        seq_ids = list(range(batch))
+        toks = [model.forward(prompts, seq_ids, [])]
+        logits = []
+        cur = list(lens)
+        for step in range(8):
+            cur = [n + 1 for n in cur]
+            feed = forced[step] if forced is not None else toks[-1]
+            toks.append(model.forward([[t] for t in feed], seq_ids, list(cur)))
+            logits.append(model.post_layer.logits_tap[-1].float().cpu())
+        del model
+        torch.cuda.empty_cache()
+        return toks, logits
+
+    ref_toks, ref_logits = run(dict(tiny_decode_batches=False))
+    eps = 2.0 ** -10 if dtype == "float16" else 2.0 ** -7
+    for opts in (dict(), dict(use_hip_graph=True)):
+        toks, logits = run(opts, forced=ref_toks)
+        for step, (a, b) in enumerate(zip(logits, ref_logits)):
+            scale = b.abs().amax(dim=1, keepdim=True).clamp(min=1.0)
+            assert ((a - b).abs() <= 4 * eps * scale).all(), (opts, step, ((a - b).abs() / scale).max().item())
+        for step, (x, y) in enumerate(zip(toks, ref_toks)):
+            for seq, (tx, ty) in enumerate(zip(x, y)):
+                if tx != ty:
+                    top2 = ref_logits[step - 1][seq].topk(2).values if step else None
+                    assert top2 is not None and float(top2[0] - top2[1]) <= 8 * eps * float(top2[0].abs().clamp(min=1.0))

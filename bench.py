@@ -285,7 +285,8 @@ def attention_roofline(model, lens, iters):
     slab_bytes = part.k_splits * B * part.shape[1] * 4 if isinstance(part, SplitKPartials) else B * H * D * e
     alg_bytes = kv_bytes + slab_bytes + B * H * D * e + part_bytes
     gbs = alg_bytes / (us * 1e-6) / 1e9
-    traffic, src = _pmc_traffic("r01_paged_attn_pmc.json", alg_bytes, (H, KVH, D) == (32, 8, 128) and nsb == 1)
+    pmc_name = "r02l_paged_attn_qkv_mfma_pmc.json" if isinstance(part, SplitKPartials) else "r01_paged_attn_pmc.json"
+    traffic, src = _pmc_traffic(pmc_name, alg_bytes, (H, KVH, D) == (32, 8, 128) and nsb == 1)
     return dict(bound="hbm", kernel=entry, achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(gbs / HBM_PEAK_GBS, 4), frac_of_measured_copy=round(gbs / HBM_COPY_GBS, 4),
                 traffic=traffic, traffic_source=src, bytes_per_launch=int(alg_bytes), us_per_launch=round(us, 2),

@@ -394,16 +394,23 @@ constexpr int kMaxNormK = 4096; // XNORM: K-chunk whose norm weight fits the 8 K
 // sequential bursts instead of 32 row segments of 256 B per tile (stream probe: 5.7-5.9 TB/s with 256-B row
 // segments, 6.2-6.4 TB/s with KiB runs). Same MFMA order as the row-major kernels, hence the same bits. RD = ring
 // depth (3 for K-chunks of >= 8 tiles, 2 for shorter ones).
-template <typename T, int MODE, bool XNORM = false, int EPI = kEpiNone, bool PACKED = false, int RD = kRing>
+// NWV = waves per workgroup: 4, or 3 (packed W, partial slabs only) for projections whose tile count is a multiple of
+// three — the fused qkv projection of Llama-3-8B is 192 tiles x 4 K-splits = 768 wave-chunks: 192 four-wave workgroups
+// leave a quarter of the 256 CUs idle, 256 three-wave ones fill the chip (r02). Three waves stage the 8 row-groups of the
+// x tile as 3 + 3 + 2: the ninth (dummy) group is a clamped load into four spare LDS rows — no branch in the pipeline.
+template <typename T, int MODE, bool XNORM = false, int EPI = kEpiNone, bool PACKED = false, int RD = kRing,
+          int NWV = kGemmWaves>
 // 2 waves per SIMD: the ring holds RD x 8 KiB of W per wave in registers (~220 VGPRs at RD = 3)
-__global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_skinny_ring_kernel(
+__global__ __launch_bounds__(NWV * 64, 2) void gemm_skinny_ring_kernel(
     void *__restrict__ out_, const T *__restrict__ x, const T *__restrict__ w, int M, int N, int K,
     int kc, int64_t x_stride, int64_t out_stride, GemmFuse fuse) {
     static_assert(!PACKED || (!XNORM && EPI == kEpiNone), "the fusion hooks are built on the row-major kernels");
+    static_assert(NWV == kGemmWaves || (NWV == 3 && PACKED && MODE == kGemmPartial), "3 waves: packed partial only");
     constexpr int D = RD;
-    constexpr int XL = 8 / kGemmWaves; // x row-groups (4 rows each) a wave stages per tile
+    constexpr int XL = (8 + NWV - 1) / NWV; // x row-groups (4 rows each) a wave stages per tile
+    constexpr int XROWS = 4 * XL * NWV;      // 32, or 36 with the dummy group of the 3-wave variant
     // [0..1] the double-buffered x tile of the workgroup, [2 + wave] the wave-private W tile (row-major W only)
-    __shared__ __attribute__((aligned(16))) T lds[2 + (PACKED ? 0 : kGemmWaves)][32 * kKT];
+    __shared__ __attribute__((aligned(16))) T lds[2 + (PACKED ? 0 : kGemmWaves)][XROWS * kKT];
     __shared__ __attribute__((aligned(16))) T gl[XNORM ? kMaxNormK : 8]; // norm weight of the K-chunk
     __shared__ float rs[32];                                              // XNORM: 1/rms per row
 
@@ -411,7 +418,7 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_skinny_ring_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool is_gate = MODE == kGemmSiluGate && wave >= 2;
     const int col0 = MODE == kGemmSiluGate ? (blockIdx.x * 2 + (wave & 1)) * 32
-                                           : (blockIdx.x * kGemmWaves + wave) * 32;
+                                           : (blockIdx.x * NWV + wave) * 32;
     const bool tile_ok = col0 < N; // barriers below: a wave without a tile still stages x and syncs
     const int n0 = tile_ok ? col0 + (is_gate ? N : 0) : 0;
     const int ksplit = blockIdx.y;
@@ -918,6 +925,27 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(T *__restrict__ dst, c
     }
 }
 
+// Partial slabs on a packed weight whose tile count divides by three and fills the chip better in three-wave workgroups
+// (see gemm_skinny_ring_kernel's NWV): same bits, other launch geometry.
+static bool prefer_three_waves(int N, int ks) {
+    const int tiles = N / 32;
+    if (tiles % 3 != 0) return false;
+    const int wg4 = (tiles + kGemmWaves - 1) / kGemmWaves * ks, wg3 = tiles / 3 * ks;
+    return wg4 < 256 && wg3 <= 256;
+}
+
+template <typename T>
+static void launch_packed_partial3(hipStream_t stream, void *out, const T *x, const T *wp, int M, int N, int K, int kc,
+                                   int ks, int64_t xs) {
+    const dim3 grid(N / 32 / 3, ks);
+    if (use_ring(kc))
+        hipLaunchKernelGGL((gemm_skinny_ring_kernel<T, kGemmPartial, false, kEpiNone, true, 3, 3>), grid, dim3(3 * 64), 0,
+                           stream, out, x, wp, M, N, K, kc, xs, static_cast<int64_t>(N), GemmFuse{});
+    else
+        hipLaunchKernelGGL((gemm_skinny_ring_kernel<T, kGemmPartial, false, kEpiNone, true, 2, 3>), grid, dim3(3 * 64), 0,
+                           stream, out, x, wp, M, N, K, kc, xs, static_cast<int64_t>(N), GemmFuse{});
+}
+
 template <typename T, int MODE>
 static void launch_packed(dim3 grid, hipStream_t stream, void *out, const T *x, const T *wp, int M, int N, int K, int kc,
                           int64_t xs, int64_t os, const GemmFuse &fuse = GemmFuse{}) {
@@ -941,7 +969,8 @@ static int run_gemm_packed(T *out, const T *x, const T *wp, float *ws, size_t ws
         return check_launch();
     }
     if (!ws || ws_bytes < static_cast<size_t>(ks) * M * N * sizeof(float)) return SWL_ERR_BAD_ARG;
-    launch_packed<T, kGemmPartial>(grid, stream, ws, x, wp, M, N, K, kc, xs, static_cast<int64_t>(N));
+    if (prefer_three_waves(N, ks)) launch_packed_partial3<T>(stream, ws, x, wp, M, N, K, kc, ks, xs);
+    else launch_packed<T, kGemmPartial>(grid, stream, ws, x, wp, M, N, K, kc, xs, static_cast<int64_t>(N));
     if (!reduce) return check_launch();
     const int64_t items = static_cast<int64_t>(M) * (N / 4);
     hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(static_cast<unsigned>((items + 255) / 256)), dim3(256), 0,

@@ -1044,3 +1044,64 @@ def test_tiny_batch_projections_equal_consumer_plus_gemm(dtype, M, hid, N, inter
     ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
     err = (act_new.float() - act_ref.float()).abs()
     assert (err <= 4 * ulp * act_ref.float().abs() + 1e-5).all(), err.max().item()
+
+
+# ---- projections with K split inside the workgroup (gemm_wgk.hip) --------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [1, 7, 32])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (6144, 4096), (4096, 14336), (256, 1024), (96, 3072)])
+def test_in_workgroup_split_k_projection(dtype, M, N, K):
+    """swl_gemm_wgk / swl_gemm_wgk_add_scale: the direct output against an fp64 product (and, rounded, against the
+    split-K kernel's 8-slab sum — same K partition, same order, hence the same bits); the add+scale epilogue against
+    swl_gemm_skinny_packed_partial (8 splits) + swl_splitk_add_scale bit for bit on residual and x_scaled, sums of squares
+    to fp32 rounding; the deferred 1/rms against the scaled product."""
+    from swiftllm_amd import _hip
+    lib = _hip.load()
+    if not lib.swl_gemm_wgk_supported(M, N, K):
+        pytest.skip("shape outside the kernel's limits")
+    g = gen(N + K + M)
+    code = _hip.dtype_code(dtype)
+    x = torch.randn(M, K, generator=g).to(dtype).cuda()
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dtype).cuda()
+    wp = torch.empty_like(w)
+    _hip.call("swl_gemm_pack_weight", wp.data_ptr(), w.data_ptr(), N, K, code, _hip.stream())
+    ref = x.double().cpu() @ w.double().cpu().t()
+    # direct, fp32 out
+    o32 = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    _hip.call("swl_gemm_wgk", o32.data_ptr(), 1, x.data_ptr(), wp.data_ptr(), None, 0, 0, 0.0, M, N, K, K, N, code,
+              _hip.stream())
+    assert (o32.double().cpu() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    # direct, storage dtype == the split-K kernel with 8 slabs, reduced
+    oT = torch.empty(M, N, dtype=dtype, device="cuda")
+    _hip.call("swl_gemm_wgk", oT.data_ptr(), 0, x.data_ptr(), wp.data_ptr(), None, 0, 0, 0.0, M, N, K, K, N, code,
+              _hip.stream())
+    ws = torch.empty(16 * M * N, dtype=torch.float32, device="cuda")
+    o8 = torch.empty(M, N, dtype=dtype, device="cuda")
+    _hip.call("swl_gemm_skinny_packed", o8.data_ptr(), x.data_ptr(), wp.data_ptr(), ws.data_ptr(), ws.numel() * 4, M, N, K,
+              K, N, 8, code, _hip.stream())
+    assert torch.equal(oT, o8)
+    # deferred 1/rms of the input rows
+    ssq = (torch.rand(4, M, generator=g) * K / 4 + 0.1).float().cuda()
+    oS = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    _hip.call("swl_gemm_wgk", oS.data_ptr(), 1, x.data_ptr(), wp.data_ptr(), ssq.data_ptr(), 4, M, 1e-5, M, N, K, K, N,
+              code, _hip.stream())
+    rs = 1.0 / torch.sqrt(ssq.sum(0) / K + 1e-5)
+    assert torch.allclose(oS, o32 * rs[:, None], rtol=3e-6, atol=1e-7)
+    if N % 1024:
+        return      # swl_splitk_add_scale groups its sums of squares by 1024 columns
+    # add + scale epilogue
+    nw = (1 + 0.1 * torch.randn(N, generator=g)).to(dtype).cuda()
+    res0 = torch.randn(M, N, generator=g).to(dtype).cuda()
+    r_old, r_new = res0.clone(), res0.clone()
+    xs_old, xs_new = torch.empty_like(res0), torch.empty_like(res0)
+    ssq_old = torch.zeros(N // 1024, M, dtype=torch.float32, device="cuda")
+    ssq_new = torch.zeros(N // 32, 32, dtype=torch.float32, device="cuda")
+    _hip.call("swl_gemm_skinny_packed_partial", ws.data_ptr(), ws.numel() * 4, x.data_ptr(), wp.data_ptr(), M, N, K, K, 8,
+              code, _hip.stream())
+    _hip.call("swl_splitk_add_scale", xs_old.data_ptr(), r_old.data_ptr(), nw.data_ptr(), ws.data_ptr(), 8,
+              ssq_old.data_ptr(), M, N, code, _hip.stream())
+    _hip.call("swl_gemm_wgk_add_scale", xs_new.data_ptr(), r_new.data_ptr(), ssq_new.data_ptr(), nw.data_ptr(),
+              x.data_ptr(), wp.data_ptr(), M, N, K, K, code, _hip.stream())
+    assert torch.equal(r_new, r_old) and torch.equal(xs_new, xs_old)
+    so, sn = ssq_old.sum(0), ssq_new[:, :M].sum(0)
+    assert ((so - sn).abs() <= 2e-6 * so).all()

@@ -396,6 +396,26 @@ int swl_gemm_wgk_add_scale(void *x_scaled, void *residual, float *ssq_out, const
  *     (ssq_parts = k_splits_out). slabs_out != slabs_in.
  *   swl_gemm_tiny_silu_gate_from_splitk: the FFN up/gate projection + SiLU-gate (transformer_layer.py:120-127):
  *     out[M, I] = up * silu(gate) of rstd[m] * (x . [up ; gate]^T), rstd from the same rows. I % 64 == 0, K <= 4096. */
+/*   swl_paged_attn_decode_qkv_rs_partials: swl_paged_attn_decode_qkv_rs stopped after phase 1 when num_seq_blocks > 1 — the
+ *     flash-decoding partials stay in `scratch` (mid_o fp32 [Bd][H][nsb][D], then mid_lse fp32 [Bd][H][nsb]; reference
+ *     paged_attn.py:106-108), `o` may be NULL; with num_seq_blocks == 1 it is swl_paged_attn_decode_qkv_rs.
+ *   swl_gemm_tiny_partial_from_attn: o_proj (transformer_layer.py:117) on those partials — every workgroup merges the
+ *     partials of its K-chunk of heads itself (phase 2's LSE-weighted sum, paged_attn.py:108-150, rounded to the storage
+ *     dtype as phase 2 stores it) and writes slabs_out[k_splits_out][M][N]; K = num_q_heads * head_dim. Replaces the
+ *     phase-2 launch of a batch of <= 4 sequences. */
+int swl_paged_attn_decode_qkv_rs_partials(void *o, const float *qkv_slabs, int32_t k_splits, const float *row_ssq,
+                                          int32_t ssq_parts, int32_t hidden, float eps, const void *cos_table,
+                                          const void *sin_table, const int32_t *pos_idx, void *k_cache, void *v_cache,
+                                          const int32_t *block_table, const int32_t *seq_ids, const int32_t *seq_lens,
+                                          void *scratch, float softmax_scale, int32_t num_decoding_seqs,
+                                          int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
+                                          int32_t num_layers, int32_t block_size, int32_t cur_layer,
+                                          int32_t max_blocks_per_seq, int32_t seq_block_size, int32_t num_seq_blocks,
+                                          int64_t o_tok_stride, int32_t dtype, swl_stream_t stream);
+int swl_gemm_tiny_partial_from_attn(float *slabs_out, size_t slabs_out_bytes, int32_t k_splits_out,
+                                    const float *attn_scratch, const int32_t *seq_lens, int32_t num_q_heads,
+                                    int32_t head_dim, int32_t seq_block_size, int32_t num_seq_blocks,
+                                    const void *w_packed, int32_t M, int32_t N, int32_t dtype, swl_stream_t stream);
 int swl_gemm_tiny_max_tokens(void);
 int swl_gemm_tiny_partial_from_splitk(float *slabs_out, size_t slabs_out_bytes, int32_t k_splits_out, float *ssq_out,
                                       const float *slabs_in, int32_t k_splits_in, const void *residual_in,

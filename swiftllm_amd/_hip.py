@@ -80,6 +80,9 @@ SIGNATURES = {
                                           _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _P],
     "swl_gemm_wgk": [_P, _I32, _P, _P, _P, _I32, _I32, _F32, _I32, _I32, _I32, _I64, _I64, _I32, _P],
     "swl_gemm_wgk_add_scale": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I64, _I32, _P],
+    "swl_paged_attn_decode_qkv_rs_partials": [_P, _P, _I32, _P, _I32, _I32, _F32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F32,
+                                              _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I32, _P],
+    "swl_gemm_tiny_partial_from_attn": [_P, ctypes.c_size_t, _I32, _P, _P, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _P],
     "swl_gemm_tiny_partial_from_splitk": [_P, ctypes.c_size_t, _I32, _P, _P, _I32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
     "swl_gemm_tiny_silu_gate_from_splitk": [_P, _P, _I32, _P, _P, _P, _F32, _P, _I32, _I32, _I32, _I64, _I32, _P],
 }

@@ -34,6 +34,7 @@ constexpr int kTinyMaxKc = 4096;  // K-chunk resident in LDS: 4 rows x 4096 x 2 
 constexpr int kTinyPitch = kTinyMaxKc + 8;
 
 enum TinyMode { kTinyPartial = 0, kTinySiluGate = 1 };
+enum TinySrc { kTinyFromSlabs = 0, kTinyFromAttnPartials = 1 };
 
 struct TinyArgs {
     void *out;            // Partial: fp32 slabs [ks][M][N]; SiluGate: T [M][I]
@@ -47,9 +48,13 @@ struct TinyArgs {
     const void *norm_w;
     float eps;
     float *ssq_out;       // Partial: [gridDim.y][M]
+    // kTinyFromAttnPartials: x[seq][head * D + d] = LSE-weighted merge of the flash-decoding partials (paged_attn.hip phase 2)
+    const float *mid_o, *mid_lse;
+    const int *seq_lens;
+    int H, D, seq_block_size, num_seq_blocks;
 };
 
-template <typename T, int MODE>
+template <typename T, int MODE, int SRC = kTinyFromSlabs>
 __global__ __launch_bounds__(kTinyWaves * 64, 2) void gemm_tiny_kernel(TinyArgs a) {
     __shared__ __attribute__((aligned(16))) T xres[kTinyMaxM][kTinyPitch];
     __shared__ __attribute__((aligned(16))) T zero16[8];
@@ -80,9 +85,87 @@ __global__ __launch_bounds__(kTinyWaves * 64, 2) void gemm_tiny_kernel(TinyArgs 
     for (int d = 0; d < D - 1; ++d)
         if (d < nkt) SWL_TINY_ISSUE(d, d);
 
-    // ---- rebuild this K-chunk of the activations: swl_splitk_add_scale's arithmetic (rmsnorm.hip) ----
     if (threadIdx.x < 8) zero16[threadIdx.x] = to_t<T>(0.f);
     float ssq[kTinyMaxM] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (SRC == kTinyFromAttnPartials) {
+        // ---- this K-chunk of the attention output, merged from the flash-decoding partials (reference paged_attn.py:
+        // 108-150; paged_attn_phase2_kernel's arithmetic up to the fp32 order of the weight sum): one item = 8 columns
+        // of one (sequence, head); the log-sum-exps and the partial rows of up to 16 splits are requested together ----
+        const int per_row = kc >> 3;
+        for (int it = threadIdx.x; it < M * per_row; it += kTinyWaves * 64) {
+            const int row = it / per_row;
+            const int c8 = it - row * per_row;
+            const int col = k_begin + 8 * c8;
+            const int head = col / a.D, d = col - head * a.D;
+            const int n = (a.seq_lens[row] + a.seq_block_size - 1) / a.seq_block_size;
+            const int64_t base = (static_cast<int64_t>(row) * a.H + head) * a.num_seq_blocks;
+            float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            float lsum = 0.f;
+            if (n <= 16) {
+                // the common case in ONE round trip: the partial rows do not depend on the log-sum-exps, only their
+                // weights do — everything is requested before the first use
+                float lse[16];
+                float4_t va[16], vb[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int sidx = min(u, n - 1);
+                    lse[u] = a.mid_lse[base + sidx];
+                    const float *src = a.mid_o + (base + sidx) * a.D + d;
+                    va[u] = *reinterpret_cast<const float4_t *>(src);
+                    vb[u] = *reinterpret_cast<const float4_t *>(src + 4);
+                }
+                float mx = kNegBig;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) mx = fmaxf(mx, lse[u]);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const float wgt = u < n ? fast_exp2(lse[u] - mx) : 0.f;
+                    lsum += wgt;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc8[e] = fmaf(wgt, va[u][e], acc8[e]);
+                        acc8[4 + e] = fmaf(wgt, vb[u][e], acc8[4 + e]);
+                    }
+                }
+            } else {
+                float mx = kNegBig;
+                for (int s0 = 0; s0 < n; s0 += 16) {
+                    float t16[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) t16[u] = a.mid_lse[base + min(s0 + u, n - 1)];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) mx = fmaxf(mx, t16[u]);
+                }
+                for (int s0 = 0; s0 < n; s0 += 8) {
+                    float lse[8];
+                    float4_t va[8], vb[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int sidx = min(s0 + u, n - 1);
+                        lse[u] = a.mid_lse[base + sidx];
+                        const float *src = a.mid_o + (base + sidx) * a.D + d;
+                        va[u] = *reinterpret_cast<const float4_t *>(src);
+                        vb[u] = *reinterpret_cast<const float4_t *>(src + 4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float wgt = s0 + u < n ? fast_exp2(lse[u] - mx) : 0.f;
+                        lsum += wgt;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc8[e] = fmaf(wgt, va[u][e], acc8[e]);
+                            acc8[4 + e] = fmaf(wgt, vb[u][e], acc8[4 + e]);
+                        }
+                    }
+                }
+            }
+            vec8_t<T> sv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sv[j] = to_t<T>(acc8[j] / lsum);
+            *reinterpret_cast<vec8_t<T> *>(&xres[row][8 * c8]) = sv;
+        }
+    } else {
+    // ---- rebuild this K-chunk of the activations: swl_splitk_add_scale's arithmetic (rmsnorm.hip) ----
     {
         const int per_row = kc >> 3; // items (8 columns) per row
         const int64_t slab_stride = static_cast<int64_t>(M) * K;
@@ -129,8 +212,9 @@ __global__ __launch_bounds__(kTinyWaves * 64, 2) void gemm_tiny_kernel(TinyArgs 
             if (lane == 0) red[wave][r] = tot;
         }
     }
+    } // SRC
     __syncthreads();
-    if (threadIdx.x < kTinyMaxM) {
+    if (SRC == kTinyFromSlabs && threadIdx.x < kTinyMaxM) {
         const float tot = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
         if constexpr (MODE == kTinySiluGate) rs_s[threadIdx.x] = 1.0f / sqrtf(tot / static_cast<float>(K) + a.eps);
         else if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < M) a.ssq_out[ksplit * M + threadIdx.x] = tot;
@@ -238,6 +322,36 @@ extern "C" int swl_gemm_tiny_partial_from_splitk(float *slabs_out, size_t slabs_
     SWL_DISPATCH_DTYPE(dtype, T, {
         hipLaunchKernelGGL((swl::gemm_tiny_kernel<T, swl::kTinyPartial>), grid, dim3(swl::kTinyWaves * 64), 0,
                            static_cast<hipStream_t>(stream), a);
+    });
+    return swl::check_launch();
+}
+
+extern "C" int swl_gemm_tiny_partial_from_attn(float *slabs_out, size_t slabs_out_bytes, int32_t k_splits_out,
+                                               const float *attn_scratch, const int32_t *seq_lens,
+                                               int32_t num_q_heads, int32_t head_dim, int32_t seq_block_size,
+                                               int32_t num_seq_blocks, const void *w_packed, int32_t M, int32_t N,
+                                               int32_t dtype, swl_stream_t stream) {
+    if (M < 0 || N <= 0 || k_splits_out <= 0 || num_q_heads <= 0 || head_dim <= 0 || seq_block_size <= 0 ||
+        num_seq_blocks <= 0)
+        return SWL_ERR_BAD_ARG;
+    if (M == 0) return SWL_OK;
+    if (!slabs_out || !attn_scratch || !seq_lens || !w_packed) return SWL_ERR_BAD_ARG;
+    const int K = num_q_heads * head_dim;
+    if ((head_dim & 7) || K % k_splits_out != 0 || !swl::tiny_common_ok(M, N, K, K / k_splits_out))
+        return SWL_ERR_UNSUPPORTED;
+    if (slabs_out_bytes < static_cast<size_t>(k_splits_out) * M * N * sizeof(float)) return SWL_ERR_BAD_ARG;
+    if (!swl::aligned16(slabs_out) || !swl::aligned16(attn_scratch) || !swl::aligned16(w_packed)) return SWL_ERR_BAD_ARG;
+    swl::TinyArgs a = {};
+    a.out = slabs_out; a.wp = w_packed;
+    a.M = M; a.N = N; a.K = K; a.kc = K / k_splits_out; a.out_stride = N;
+    a.mid_o = attn_scratch;
+    a.mid_lse = attn_scratch + static_cast<size_t>(M) * num_q_heads * num_seq_blocks * head_dim;
+    a.seq_lens = seq_lens;
+    a.H = num_q_heads; a.D = head_dim; a.seq_block_size = seq_block_size; a.num_seq_blocks = num_seq_blocks;
+    const dim3 grid((N / 32 + swl::kTinyWaves - 1) / swl::kTinyWaves, k_splits_out);
+    SWL_DISPATCH_DTYPE(dtype, T, {
+        hipLaunchKernelGGL((swl::gemm_tiny_kernel<T, swl::kTinyPartial, swl::kTinyFromAttnPartials>), grid,
+                           dim3(swl::kTinyWaves * 64), 0, static_cast<hipStream_t>(stream), a);
     });
     return swl::check_launch();
 }

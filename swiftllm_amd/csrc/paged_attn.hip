@@ -936,7 +936,7 @@ static int paged_attn_decode_qkv_impl(void *o, const float *qkv_slabs, int32_t k
                                       int32_t block_size, int32_t cur_layer, int32_t max_blocks_per_seq,
                                       int32_t seq_block_size, int32_t num_seq_blocks, int64_t o_tok_stride, int32_t dtype,
                                       swl_stream_t stream, const float *row_ssq, int32_t ssq_parts, int32_t hidden,
-                                      float eps);
+                                      float eps, bool merge = true);
 
 extern "C" int swl_paged_attn_decode_qkv(void *o, const float *qkv_slabs, int32_t k_splits, const void *cos_table,
                                          const void *sin_table, const int32_t *pos_idx, void *k_cache,
@@ -986,10 +986,10 @@ static int paged_attn_decode_qkv_impl(void *o, const float *qkv_slabs, int32_t k
                                          int32_t cur_layer, int32_t max_blocks_per_seq, int32_t seq_block_size,
                                          int32_t num_seq_blocks, int64_t o_tok_stride, int32_t dtype,
                                          swl_stream_t stream, const float *row_ssq, int32_t ssq_parts, int32_t hidden,
-                                         float eps) {
+                                         float eps, bool merge) {
     if (num_decoding_seqs < 0) return SWL_ERR_BAD_ARG;
     if (num_decoding_seqs == 0 || num_seq_blocks == 0) return SWL_OK;
-    if (!o || !qkv_slabs || !cos_table || !sin_table || !k_cache || !v_cache || !block_table || !seq_ids ||
+    if ((!o && (merge || num_seq_blocks == 1)) || !qkv_slabs || !cos_table || !sin_table || !k_cache || !v_cache || !block_table || !seq_ids ||
         !seq_lens || k_splits <= 0)
         return SWL_ERR_BAD_ARG;
     if (num_seq_blocks < 0 || num_q_heads <= 0 || num_kv_heads <= 0 || num_q_heads % num_kv_heads != 0 ||
@@ -1039,7 +1039,32 @@ static int paged_attn_decode_qkv_impl(void *o, const float *qkv_slabs, int32_t k
     SWL_DISPATCH_DTYPE(dtype, T, {
         rc = swl::dispatch_phase1<T, true>(p, num_decoding_seqs, head_dim, G, static_cast<hipStream_t>(stream));
     });
-    if (rc != SWL_OK || num_seq_blocks == 1) return rc;
+    if (rc != SWL_OK || num_seq_blocks == 1 || !merge) return rc;
     return swl_paged_attn_phase2(o, mid_o, mid_lse, seq_lens, num_decoding_seqs, num_q_heads, head_dim,
                                  seq_block_size, num_seq_blocks, o_tok_stride, dtype, stream);
+}
+
+/* swl_paged_attn_decode_qkv_rs stopped after phase 1 when the sequences are split (num_seq_blocks > 1): the partials stay
+ * in `scratch` (mid_o fp32 [Bd][H][nsb][D] followed by mid_lse fp32 [Bd][H][nsb], the reference's format,
+ * paged_attn.py:106-108) for a consumer that merges them itself (swl_gemm_tiny_partial_from_attn). With one split per
+ * sequence it is swl_paged_attn_decode_qkv_rs: the output goes to `o`. */
+extern "C" int swl_paged_attn_decode_qkv_rs_partials(void *o, const float *qkv_slabs, int32_t k_splits,
+                                                     const float *row_ssq, int32_t ssq_parts, int32_t hidden, float eps,
+                                                     const void *cos_table, const void *sin_table,
+                                                     const int32_t *pos_idx, void *k_cache, void *v_cache,
+                                                     const int32_t *block_table, const int32_t *seq_ids,
+                                                     const int32_t *seq_lens, void *scratch, float softmax_scale,
+                                                     int32_t num_decoding_seqs, int32_t num_q_heads,
+                                                     int32_t num_kv_heads, int32_t head_dim, int32_t num_layers,
+                                                     int32_t block_size, int32_t cur_layer, int32_t max_blocks_per_seq,
+                                                     int32_t seq_block_size, int32_t num_seq_blocks,
+                                                     int64_t o_tok_stride, int32_t dtype, swl_stream_t stream) {
+    if (num_decoding_seqs == 0 || num_seq_blocks == 0) return num_decoding_seqs < 0 ? SWL_ERR_BAD_ARG : SWL_OK;
+    if (!row_ssq || ssq_parts <= 0 || hidden <= 0) return SWL_ERR_BAD_ARG;
+    if (ssq_parts > 8 || !(k_splits == 1 || k_splits == 2 || k_splits == 4)) return SWL_ERR_UNSUPPORTED;
+    return paged_attn_decode_qkv_impl(o, qkv_slabs, k_splits, cos_table, sin_table, pos_idx, k_cache, v_cache, block_table,
+                                      seq_ids, seq_lens, scratch, softmax_scale, num_decoding_seqs, num_q_heads,
+                                      num_kv_heads, head_dim, num_layers, block_size, cur_layer, max_blocks_per_seq,
+                                      seq_block_size, num_seq_blocks, o_tok_stride, dtype, stream, row_ssq, ssq_parts,
+                                      hidden, eps, false);
 }

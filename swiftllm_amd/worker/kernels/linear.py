@@ -263,6 +263,33 @@ def linear_splitk_from_splitk(partials, residual_in: torch.Tensor, residual_out:
     return SplitKPartials(ws, ks, m, n, partials.dtype), ssq
 
 
+def attn_partials_ok(num_tokens: int, num_q_heads: int, head_dim: int, w: torch.Tensor) -> bool:
+    """Can `w`'s projection (o_proj) merge the flash-decoding partials of `num_tokens` sequences itself?"""
+    if _packed_of(w) is None or not (0 < num_tokens <= _TINY_MAX_M) or head_dim % 8:
+        return False
+    n, k = w.shape
+    if k != num_q_heads * head_dim or n % 32 or k % 128:
+        return False
+    ks = _hip.load().swl_gemm_skinny_choose_splits(n, k)
+    return ks > 1 and k % ks == 0 and (k // ks) % 128 == 0 and k // ks <= _TINY_MAX_KC
+
+
+def linear_splitk_from_attn_partials(scratch: torch.Tensor, seq_lens: torch.Tensor, num_tokens: int, num_q_heads: int,
+                                     head_dim: int, seq_block_size: int, num_seq_blocks: int, w: torch.Tensor,
+                                     dtype: torch.dtype):
+    """o_proj on the partials of a split flash-decoding (paged_attention_from_qkv_splitk(..., merge=False)): every
+    workgroup merges the partials of its K-chunk of heads itself; returns the projection's SplitKPartials. One launch
+    instead of the phase-2 merge + linear_splitk."""
+    assert attn_partials_ok(num_tokens, num_q_heads, head_dim, w) and num_seq_blocks > 1
+    n, k = w.shape
+    ks = _hip.load().swl_gemm_skinny_choose_splits(n, k)
+    ws = _workspace(scratch.device, ks * num_tokens * n * 4)
+    _hip.call("swl_gemm_tiny_partial_from_attn", _hip.ptr(ws), ws.numel() * 4, ks, _hip.ptr(scratch), _hip.ptr(seq_lens),
+              num_q_heads, head_dim, seq_block_size, num_seq_blocks, _hip.ptr(_packed_of(w)), num_tokens, n,
+              _hip.dtype_code(dtype), _hip.stream())
+    return SplitKPartials(ws, ks, num_tokens, n, dtype)
+
+
 def linear_silu_gate_from_splitk(partials, residual_in: torch.Tensor, residual_out: torch.Tensor, norm_w: torch.Tensor,
                                  eps: float, w_up_gate: torch.Tensor) -> torch.Tensor:
     """residual_out = round(sum of `partials`) + residual_in; returns silu_and_mul(rmsnorm(residual_out) @ up_gate^T)

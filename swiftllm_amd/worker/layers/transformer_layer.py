@@ -34,6 +34,7 @@ import torch
 from ..kernels.linear import (NormPending, SplitKPartials, fused_layer_ok, linear, linear_add_residual,
                               linear_norm_silu_gate, linear_qkv_rope_store, linear_silu_gate, linear_splitk)
 from ..kernels.linear import _TINY_POLICY_M as TINY_POLICY_M
+from ..kernels.linear import attn_partials_ok, linear_splitk_from_attn_partials
 from ..kernels.linear import (row_scaled_silu_gate_ok, alt_residual_like, linear_silu_gate_from_splitk,
                               linear_splitk_from_splitk, tiny_from_splitk_ok)
 from ..kernels.rmsnorm import RowScalePending
@@ -142,10 +143,20 @@ class LlamaTransformerLayer:
         alt = alt_residual_like(residual_buf)
         # residual_buf + down slabs -> alt ; qkv slabs of round(alt * attn_norm), 1/rms pending
         qkv, ssq = linear_splitk_from_splitk(partials, residual_buf, alt, w.attn_norm, w.qkv_proj)
-        o = torch.empty_like(residual_buf)
-        paged_attention_from_qkv_splitk(qkv, k_cache, v_cache, block_table, cfg, ecfg, st, self.layer_id, o,
-                                        row_scale=RowScalePending(None, ssq, qkv.k_splits, eps, cfg.hidden_size))
-        attn_out = linear_splitk(o, w.o_proj)
+        pend = RowScalePending(None, ssq, qkv.k_splits, eps, cfg.hidden_size)
+        m = residual_buf.shape[0]
+        if st.num_seq_blocks > 1 and attn_partials_ok(m, cfg.num_q_heads, cfg.head_dim, w.o_proj):
+            # split sequences: no phase-2 launch — o_proj merges the partials of its K-chunk of heads itself
+            scratch = paged_attention_from_qkv_splitk(qkv, k_cache, v_cache, block_table, cfg, ecfg, st, self.layer_id,
+                                                      None, row_scale=pend, merge=False)
+            attn_out = linear_splitk_from_attn_partials(scratch, st.decoding_seq_lens, m, cfg.num_q_heads, cfg.head_dim,
+                                                        st.seq_block_size, st.num_seq_blocks, w.o_proj,
+                                                        residual_buf.dtype)
+        else:
+            o = torch.empty_like(residual_buf)
+            paged_attention_from_qkv_splitk(qkv, k_cache, v_cache, block_table, cfg, ecfg, st, self.layer_id, o,
+                                            row_scale=pend)
+            attn_out = linear_splitk(o, w.o_proj)
         assert isinstance(attn_out, SplitKPartials)
         # alt + o_proj slabs -> residual_buf ; up * silu(gate) of rmsnorm(residual_buf)
         act = linear_silu_gate_from_splitk(attn_out, alt, residual_buf, w.ffn_norm, eps, w.up_gate_proj)

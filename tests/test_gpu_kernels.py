@@ -1105,3 +1105,48 @@ def test_in_workgroup_split_k_projection(dtype, M, N, K):
     assert torch.equal(r_new, r_old) and torch.equal(xs_new, xs_old)
     so, sn = ssq_old.sum(0), ssq_new[:, :M].sum(0)
     assert ((so - sn).abs() <= 2e-6 * so).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [1, 2, 4])
+def test_tiny_batch_o_proj_merges_attention_partials(dtype, M):
+    """linear_splitk_from_attn_partials (o_proj that merges the flash-decoding partials itself) against phase 2 +
+    linear_splitk: the merged rows may differ from phase 2's by the fp32 order of the weight sum (one ulp of the storage
+    dtype, rarely), so the projections agree to a few ulp of their own scale and almost everywhere exactly."""
+    import importlib
+    from swiftllm_amd import _hip
+    L = importlib.import_module("swiftllm_amd.worker.kernels.linear")
+    H, D, nsb, sbs = 32, 128, 6, 64
+    hid = H * D
+    g = gen(M * 13 + 5)
+    lens = [300, 70, 64, 381][:M]
+    w = (torch.randn(hid, hid, generator=g) * hid ** -0.5).to(dtype).cuda()
+    L.pack_weight(w)
+    mid_o = torch.randn(M, H, nsb, D, generator=g).float()
+    mid_lse = (torch.randn(M, H, nsb, generator=g) * 3).float()
+    scratch = torch.cat([mid_o.view(-1), mid_lse.view(-1)]).cuda()
+    seq_lens = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    assert L.attn_partials_ok(M, H, D, w)
+    # reference: the phase-2 kernel, then the ordinary split-K projection
+    o = torch.empty(M, H, D, dtype=dtype, device="cuda")
+    mo = scratch[: M * H * nsb * D]
+    ml = scratch[M * H * nsb * D:]
+    _hip.call("swl_paged_attn_phase2", o.data_ptr(), mo.data_ptr(), ml.data_ptr(), seq_lens.data_ptr(), M, H, D, sbs, nsb,
+              H * D, _hip.dtype_code(dtype), _hip.stream())
+    ref = L.linear_splitk(o.view(M, hid), w)
+    ref_out = ref.materialize().float() if isinstance(ref, L.SplitKPartials) else ref.float()
+    new = L.linear_splitk_from_attn_partials(scratch, seq_lens, M, H, D, sbs, nsb, w, dtype)
+    new_out = new.materialize().float()
+    # also against an fp64 merge + product
+    n_used = [-(-n // sbs) for n in lens]
+    x64 = torch.zeros(M, hid, dtype=torch.float64)
+    for m_ in range(M):
+        for h in range(H):
+            lw = torch.exp2((mid_lse[m_, h, :n_used[m_]] - mid_lse[m_, h, :n_used[m_]].max()).double())
+            x64[m_, h * D:(h + 1) * D] = (lw[:, None] * mid_o[m_, h, :n_used[m_]].double()).sum(0) / lw.sum()
+    out64 = x64.to(dtype).double() @ w.double().cpu().t()
+    eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    scale = max(1.0, float(out64.abs().max()))
+    assert (new_out.double().cpu() - out64).abs().max().item() <= 4 * eps * scale
+    assert (new_out - ref_out).abs().max().item() <= 4 * eps * scale
+    assert (new_out == ref_out).float().mean().item() > 0.9

@@ -306,7 +306,10 @@ int swl_gemm_skinny_qkv_rope_store(void *q_out, const void *x, const float *ssq_
  *   o_proj / down_proj  -> swl_splitk_fused_add_rmsnorm      (reference: rmsnorm.py:39-89)
  *   fused qkv           -> swl_splitk_rotary_store_kv_decode (reference: rotary_emb.py + kvcache_mgmt.py:50-79)
  *   anything else       -> swl_splitk_reduce */
-int swl_gemm_skinny_choose_splits(int32_t N, int32_t K); /* 0 = shape unsupported, 1 = no split */
+int swl_gemm_skinny_choose_splits(int32_t N, int32_t K);
+/* ... on a packed weight (swl_gemm_skinny_packed*, k_splits = 0): splits may differ by one 128-column tile when K has no
+ * power-of-two split of whole tiles that fills the chip (Llama-2-7B down_proj: K = 11008 -> 8 splits of 10-11 tiles). */
+int swl_gemm_skinny_packed_choose_splits(int32_t N, int32_t K); /* 0 = shape unsupported, 1 = no split */
 int swl_gemm_skinny_partial(float *slabs, size_t slabs_bytes, const void *x, const void *w, int32_t M,
                             int32_t N, int32_t K, int64_t x_row_stride, int32_t k_splits,
                             int32_t dtype, swl_stream_t stream);

@@ -94,6 +94,7 @@ _SPECIAL = {
     "swl_argmax_scratch_bytes": ([_I64], ctypes.c_size_t),
     "swl_gemm_skinny_workspace_bytes": ([_I32, _I32, _I32], ctypes.c_size_t),
     "swl_gemm_skinny_choose_splits": ([_I32, _I32], _I32),
+    "swl_gemm_skinny_packed_choose_splits": ([_I32, _I32], _I32),
     "swl_gemm_packed_mid_choose_splits": ([_I32, _I32, _I32], _I32),
     "swl_gemm_wgk_supported": ([_I32, _I32, _I32], _I32),
     "swl_gemm_tiny_max_tokens": ([], _I32),

@@ -71,6 +71,10 @@ enum GemmMode {
 enum GemmEpi { kEpiNone = 0, kEpiAddResidual = 1, kEpiRopeStore = 2 };
 
 struct GemmFuse {
+    // uneven K-splits (packed ring kernel, partial slabs): > 0 = the number of 128-column K-tiles of the whole
+    // projection; split y of gridDim.y takes tiles [y * total / gridDim.y, (y + 1) * total / gridDim.y) — for K that has
+    // no power-of-two split of whole tiles (Llama-2-7B's down projection: K = 11008 = 86 tiles)
+    int k_tiles_total;
     // XNORM
     const float *ssq_in; // [ssq_parts][32] partial sums of squares of the rows of x
     const void *norm_w;  // [K]
@@ -422,8 +426,13 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_skinny_ring_kernel(
     const bool tile_ok = col0 < N; // barriers below: a wave without a tile still stages x and syncs
     const int n0 = tile_ok ? col0 + (is_gate ? N : 0) : 0;
     const int ksplit = blockIdx.y;
-    const int k_begin = ksplit * kc;
-    const int nkt = kc / kKT;
+    int k_begin = ksplit * kc;
+    int nkt = kc / kKT;
+    if (PACKED && MODE == kGemmPartial && fuse.k_tiles_total > 0) {
+        const int t0 = ksplit * fuse.k_tiles_total / static_cast<int>(gridDim.y);
+        nkt = (ksplit + 1) * fuse.k_tiles_total / static_cast<int>(gridDim.y) - t0;
+        k_begin = t0 * kKT;
+    }
 
     const int rsub = lane >> 4;
     const int chunk = lane & 15;
@@ -621,6 +630,21 @@ static int choose_k_splits(int N, int K) {
     return ks;
 }
 
+// Packed weights only: when K has no power-of-two split of whole tiles that fills the chip (the even rule above stops
+// at 2 splits = 64 workgroups for N = 4096, K = 11008), the splits may differ by one tile: the smallest power of two
+// that launches >= 768 waves with >= 8 tiles per split (ring kernel), as the even rule would have picked.
+static int choose_k_splits_packed(int N, int K, bool *uneven) {
+    const int even = choose_k_splits(N, K);
+    *uneven = false;
+    const int tiles = N / 32, ktiles = K / kKT;
+    if (tiles * even >= 512) return even;
+    int ks = even;
+    while (ks < 16 && tiles * ks < 768 && ktiles / (ks * 2) >= 8) ks *= 2;
+    if (ks == even) return even;
+    *uneven = K % (kKT * ks) != 0;
+    return ks;
+}
+
 // K-chunks of >= 8 tiles amortise the ring's barriers; shorter ones keep the barrier-free kernel.
 static bool use_ring(int kc) { return kc / kKT >= 8; }
 
@@ -662,7 +686,8 @@ static int run_gemm(T *out, const T *x, const T *w, float *ws, size_t ws_bytes, 
 
 extern "C" size_t swl_gemm_skinny_workspace_bytes(int32_t M, int32_t N, int32_t K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    const int ks = swl::choose_k_splits(N, K);
+    bool uneven = false;
+    const int ks = swl::choose_k_splits_packed(N, K, &uneven); // (>= the row-major kernels' choice)
     return ks > 1 ? static_cast<size_t>(16) * M * N * sizeof(float) : 0; // room for any legal override
 }
 
@@ -691,6 +716,14 @@ extern "C" int swl_gemm_skinny(void *out, const void *x, const void *w, void *wo
 extern "C" int swl_gemm_skinny_choose_splits(int32_t N, int32_t K) {
     if (N <= 0 || K <= 0 || (N & 31) || (K & (swl::kKT - 1))) return 0;
     return swl::choose_k_splits(N, K);
+}
+
+/* The split count swl_gemm_skinny_packed / _packed_partial pick with k_splits = 0: as above, except that splits may
+ * differ by one K-tile when K has no power-of-two split of whole tiles that fills the chip (K = 11008). */
+extern "C" int swl_gemm_skinny_packed_choose_splits(int32_t N, int32_t K) {
+    if (N <= 0 || K <= 0 || (N & 31) || (K & (swl::kKT - 1))) return 0;
+    bool uneven = false;
+    return swl::choose_k_splits_packed(N, K, &uneven);
 }
 
 /* Partial slabs only: slabs[k_splits][M][N] fp32, k_splits = swl_gemm_skinny_choose_splits(N, K) > 1. */
@@ -960,17 +993,21 @@ static void launch_packed(dim3 grid, hipStream_t stream, void *out, const T *x, 
 template <typename T>
 static int run_gemm_packed(T *out, const T *x, const T *wp, float *ws, size_t ws_bytes, int M, int N, int K, int64_t xs,
                            int64_t os, int ks, hipStream_t stream, bool reduce) {
-    if (ks <= 0) ks = choose_k_splits(N, K);
-    if (K % (kKT * ks) != 0) return SWL_ERR_UNSUPPORTED;
+    bool uneven = false;
+    if (ks <= 0) ks = choose_k_splits_packed(N, K, &uneven);
+    else uneven = K % (kKT * ks) != 0;
+    if (uneven && (K / kKT) / ks < 8) return SWL_ERR_UNSUPPORTED; // (uneven splits run the ring kernel only)
     const dim3 grid((N / 32 + kGemmWaves - 1) / kGemmWaves, ks);
-    const int kc = K / ks;
+    const int kc = uneven ? (K / kKT / ks) * kKT : K / ks;  // (uneven: the shorter chunk — selects the ring depth)
     if (ks == 1 && reduce) {
         launch_packed<T, kGemmDirect>(grid, stream, out, x, wp, M, N, K, kc, xs, os);
         return check_launch();
     }
     if (!ws || ws_bytes < static_cast<size_t>(ks) * M * N * sizeof(float)) return SWL_ERR_BAD_ARG;
-    if (prefer_three_waves(N, ks)) launch_packed_partial3<T>(stream, ws, x, wp, M, N, K, kc, ks, xs);
-    else launch_packed<T, kGemmPartial>(grid, stream, ws, x, wp, M, N, K, kc, xs, static_cast<int64_t>(N));
+    GemmFuse fuse{};
+    fuse.k_tiles_total = uneven ? K / kKT : 0;
+    if (!uneven && prefer_three_waves(N, ks)) launch_packed_partial3<T>(stream, ws, x, wp, M, N, K, kc, ks, xs);
+    else launch_packed<T, kGemmPartial>(grid, stream, ws, x, wp, M, N, K, kc, xs, static_cast<int64_t>(N), fuse);
     if (!reduce) return check_launch();
     const int64_t items = static_cast<int64_t>(M) * (N / 4);
     hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(static_cast<unsigned>((items + 255) / 256)), dim3(256), 0,

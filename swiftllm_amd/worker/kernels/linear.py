@@ -153,10 +153,11 @@ def linear_splitk(a: torch.Tensor, w: torch.Tensor, always: bool = False):
     if _skinny_ok(a, w):
         m, k = a.shape
         n = w.shape[0]
-        ks = _hip.load().swl_gemm_skinny_choose_splits(n, k)
+        wp = _packed_of(w)
+        lib = _hip.load()
+        ks = lib.swl_gemm_skinny_packed_choose_splits(n, k) if wp is not None else lib.swl_gemm_skinny_choose_splits(n, k)
         if ks > 1 or (always and ks == 1):
             ws = _workspace(a.device, ks * m * n * 4)
-            wp = _packed_of(w)
             _hip.call("swl_gemm_skinny_packed_partial" if wp is not None else "swl_gemm_skinny_partial", _hip.ptr(ws),
                       ws.numel() * 4, _hip.ptr(a), _hip.ptr(wp if wp is not None else w), m, n, k,
                       _row_stride(a), ks, _hip.dtype_code(a.dtype), _hip.stream())

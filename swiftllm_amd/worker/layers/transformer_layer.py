@@ -117,7 +117,10 @@ class LlamaTransformerLayer:
             return False
         if self._qkv_splits is None:
             from swiftllm_amd import _hip
-            self._qkv_splits = int(_hip.load().swl_gemm_skinny_choose_splits(w.qkv_proj.shape[0], w.qkv_proj.shape[1]))
+            lib = _hip.load()
+            choose = (lib.swl_gemm_skinny_packed_choose_splits if getattr(w.qkv_proj, "_swl_packed", None) is not None
+                      else lib.swl_gemm_skinny_choose_splits)     # what linear_splitk will pick for this weight
+            self._qkv_splits = int(choose(w.qkv_proj.shape[0], w.qkv_proj.shape[1]))
         return self._qkv_splits in (1, 2, 4)
 
     def _tiny_decode_applies(self, st, partials, residual_buf) -> bool:

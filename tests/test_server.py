@@ -321,3 +321,102 @@ def test_router_relays_to_live_replicas_and_balances():
     finally:
         for s in servers:
             s.should_exit = True
+
+
+@pytest.mark.gpu
+def test_router_in_front_of_two_real_replicas_on_one_gpu(tmp_path):
+    """two real `api_server` replicas (own process, own weights, own KV pool — here both on the one
+    GPU of the box, each taking a slice of its memory) behind the router app. Requests carrying token ids are spread
+    over both replicas, the answers are what a LlamaModel of the same weights generates offline, the books return to
+    zero. (On an 8-GPU node `python -m swiftllm_amd.server.router --num-replicas 8` does the same with one GPU each.)"""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    import time
+    import urllib.request
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    from fastapi.testclient import TestClient
+    from oracle import synth
+    from swiftllm_amd.server.router import ReplicaRouter, build_app
+
+    def free_port():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            return s.getsockname()[1]
+
+    cfg = synth.make_config(num_hidden_layers=2, hidden_size=256, num_attention_heads=4, num_key_value_heads=2,
+                            intermediate_size=512, vocab_size=512, max_position_embeddings=512)
+    synth.write_model_dir(str(tmp_path), cfg, synth.make_state_dict(cfg, seed=3, dtype=torch.float16))
+    ports = [free_port(), free_port()]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=os.path.dirname(os.path.dirname(__file__)))
+    urls = [f"http://127.0.0.1:{p}" for p in ports]
+    procs = []
+
+    def start(p, util):
+        procs.append(subprocess.Popen(
+            [sys.executable, "-m", "swiftllm_amd.server.api_server", "--port", str(p), "--model-path", str(tmp_path),
+             "--gpu-mem-utilization", str(util), "--num-cpu-blocks", "8", "--max-seqs-in-block-table", "64",
+             "--max-blocks-per-seq", "64", "--max-batch-size", "8", "--max-tokens-in-batch", "512"], env=env,
+            stdout=subprocess.DEVNULL, stderr=open(tmp_path / f"replica_{p}.err", "w")))
+
+    def wait_ready(u):     # GET /load answers once weights are loaded and the KV pool is profiled
+        deadline = time.time() + 240
+        while True:
+            try:
+                with urllib.request.urlopen(u + "/load", timeout=2) as r:
+                    if r.status == 200:
+                        return
+            except OSError:
+                pass
+            assert all(q.poll() is None for q in procs), "a replica died during start-up:\n" + "\n".join(
+                open(tmp_path / f"replica_{q}.err").read()[-1500:] for q in ports)
+            assert time.time() < deadline, "replicas did not come up"
+            time.sleep(0.5)
+
+    try:
+        # gpu_mem_utilization bounds what the DEVICE may have in use when a replica sizes its KV pool; sharing one GPU
+        # the second replica has to be given room above what the first already holds (one GPU each: not an issue)
+        start(ports[0], 0.08)
+        wait_ready(urls[0])
+        start(ports[1], 0.2)
+        wait_ready(urls[1])
+        router = ReplicaRouter(urls)
+        client = TestClient(build_app(router))
+        g = torch.Generator().manual_seed(1)
+        prompts = [torch.randint(0, cfg["vocab_size"], (n,), generator=g).tolist() for n in (5, 40, 17, 33, 8, 64)]
+
+        def ask(ids):
+            r = client.post("/generate", json={"prompt_token_ids": ids, "output_len": 12})
+            assert r.status_code == 200, r.text
+            return r.json()["output_token_ids"]
+
+        with ThreadPoolExecutor(max_workers=len(prompts)) as ex:
+            answers = list(ex.map(ask, prompts))
+        assert all(len(a) == 12 for a in answers)
+        loads = [json.loads(urllib.request.urlopen(u + "/load", timeout=5).read()) for u in urls]
+        assert router.outstanding == [0, 0] and all(v.get("outstanding_tokens", 0) == 0 for v in loads)
+        # the same weights offline: greedy decoding is deterministic, whichever replica served the request
+        from swiftllm_amd import EngineConfig, LlamaModel
+        model = LlamaModel(EngineConfig(model_path=str(tmp_path), use_dummy=False, block_size=16, gpu_mem_utilization=0.2,
+                                        num_cpu_blocks=8, max_seqs_in_block_table=16, max_blocks_per_seq=16,
+                                        max_batch_size=8, max_tokens_in_batch=512))
+        model.load_weights()
+        model.init_kvcache_and_swap(64)
+        for sid, (ids, got) in enumerate(zip(prompts, answers)):
+            toks = model.forward([ids], [sid], [])
+            out, n = [toks[0]], len(ids)
+            for _ in range(11):
+                n += 1
+                out.append(model.forward([[out[-1]]], [sid], [n])[0])
+            assert out == got, (sid, out, got)
+    finally:
+        for p in procs:
+            p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()

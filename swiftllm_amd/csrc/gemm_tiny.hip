@@ -1,21 +1,23 @@
-// gemm_tiny.hip — decode projections for very small batches (M <= 4 tokens) that consume the PREVIOUS projection's
-// split-K slabs themselves (gfx950, packed W).
+// gemm_tiny.hip — decode projections for very small batches (M <= 4 tokens) that build their own input from what the
+// PREVIOUS kernel left behind (gfx950, packed W).
 //
-// At batch 1 a decode layer is seven launches of which two — the split-K consumers (swl_splitk_add_scale, reference
-// rmsnorm.py:67-89 at transformer_layer.py:46,120) — move 100 KB each and still cost a full kernel boundary plus a
-// dependent round trip: 4.8 us apiece on FOUR workgroups, 10 % of the 99 us layer (profiles/r02i). With M <= 4 the
-// activation row is so small that every workgroup of the NEXT projection can afford to rebuild it: while its first
-// weight tiles are in flight it sums the slabs of its K-chunk (8 slabs x M x kc fp32 = 128 KB at M = 1, kc = 4096, from
-// L2), adds the residual, applies the norm weight, keeps the result in LDS for the whole K loop — no x traffic, no
-// barrier in the loop — and carries the sum of squares to where the deferred 1/rms is applied (its own epilogue for
-// the SiLU-gate projection; row_ssq[k_split][M] for the attention prologue after the qkv projection). Workgroups with
-// blockIdx.x == 0 also store the updated residual — into a SECOND buffer: the others are still reading the old one.
+// At batch 1 a decode layer is eight launches of which three move next to nothing and still cost a kernel boundary plus
+// a dependent round trip each: the two split-K consumers (swl_splitk_add_scale, reference rmsnorm.py:67-89 at
+// transformer_layer.py:46,120: 4.8 us apiece on FOUR workgroups) and the flash-decoding merge (paged_attn.py:108-150:
+// 4.6 us) — 14 % of the 99 us layer (profiles/r02i). With M <= 4 the activation row is so small that every workgroup of
+// the NEXT projection can afford to rebuild it while its first weight tiles are in flight, keep it in LDS for the whole
+// K loop (no x traffic, no barrier in the loop) and carry the sums of squares to where the deferred 1/rms is applied:
 //   qkv':     down slabs (layer L-1) + residual -> qkv slabs + row_ssq + residual'      (transformer_layer.py:46-56)
+//   o_proj':  flash-decoding partials            -> o_proj slabs                         (transformer_layer.py:117)
 //   up/gate': o_proj slabs + residual'          -> up * silu(gate)   + residual         (transformer_layer.py:120-127)
-// Same arithmetic and rounding points as swl_splitk_add_scale followed by swl_gemm_skinny_packed_partial /
-// swl_gemm_skinny_packed_silu_gate_rs (bit-identical: same slab order, same MFMA order, same ssq grouping is NOT needed —
-// the sum of squares is grouped by K-chunk here instead of by 1024 columns, a different fp32 summation order of the
-// same numbers).
+// From slabs: sum the 8 slabs of the K-chunk, add the residual (workgroups with blockIdx.x == 0 also store it — into a
+// SECOND buffer: the others are still reading the old one), apply the norm weight: swl_splitk_add_scale's arithmetic, then
+// the MFMA order of swl_gemm_skinny_packed_partial / _silu_gate_rs — slabs and residual come out bit-identical; only the
+// sums of squares are grouped by K-chunk instead of by 1024 columns (another fp32 order of the same numbers).
+// From attention partials: the LSE-weighted merge of phase 2 (same weights, same order of the weighted sum; the weight
+// SUM in a different fp32 order), rounded to the storage dtype as phase 2 stores it.
+// What bounds the gain: every workgroup pulls the rows it rebuilds through its own L1 at ~55 GB/s
+// (up/gate': 8 slabs x M x 16 KB): batch 1 gains 2 %, batch 2 is even, batch 4 loses — the layer uses this up to M = 2.
 #include "swl_common.h"
 
 namespace swl {

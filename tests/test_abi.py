@@ -94,3 +94,29 @@ def test_split_heuristics_are_host_side_and_stable():
     assert lib.swl_gemm_pack_weight(None, None, 4096, 4096, _hip.SWL_BF16, None) == -1
     assert lib.swl_gemm_skinny_packed(None, None, None, None, 0, 0, 4096, 4096, 4096, 4096, 0, _hip.SWL_BF16, None) == 0
     assert lib.swl_gemm_packed_mid(None, None, None, None, 0, 0, 4096, 4096, 4096, 4096, 0, _hip.SWL_BF16, None) == 0
+
+
+def test_split_choosers_are_host_functions_with_the_documented_values():
+    """swl_gemm_skinny_choose_splits / swl_gemm_skinny_packed_choose_splits / swl_gemm_wgk_supported /
+    swl_gemm_tiny_max_tokens need no device: the values the Python layer (and DESIGN.md section 4.3) relies on."""
+    from swiftllm_amd import _hip
+    lib = _hip.load()
+    even, packed = lib.swl_gemm_skinny_choose_splits, lib.swl_gemm_skinny_packed_choose_splits
+    # Llama-3-8B decode projections: the packed path keeps the even splits
+    for (n, k), ks in {(6144, 4096): 4, (4096, 4096): 8, (4096, 14336): 8, (28672, 4096): 1, (128256, 4096): 1}.items():
+        assert even(n, k) == ks and packed(n, k) == ks, (n, k)
+    # Llama-2-7B down_proj: 86 K-tiles have no power-of-two split beyond 2; the packed path splits unevenly into 8
+    assert even(4096, 11008) == 2 and packed(4096, 11008) == 8
+    assert even(12288, 4096) == packed(12288, 4096) == 2
+    # never fewer splits than the row-major kernels, never a split shorter than 8 tiles when uneven
+    for n in (32, 256, 4096, 6144):
+        for kt in (8, 17, 43, 86, 112, 129):
+            k = kt * 128
+            e, p = even(n, k), packed(n, k)
+            assert 1 <= e <= p <= 16
+            if k % (128 * p):
+                assert kt // p >= 8
+    assert even(100, 4096) == 0 and packed(4096, 100) == 0          # N % 32, K % 128
+    assert lib.swl_gemm_wgk_supported(32, 4096, 4096) == 1 and lib.swl_gemm_wgk_supported(33, 4096, 4096) == 0
+    assert lib.swl_gemm_wgk_supported(8, 4096, 11008) == 0          # K % 1024
+    assert lib.swl_gemm_tiny_max_tokens() == 4

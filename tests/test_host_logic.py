@@ -372,3 +372,33 @@ def test_graph_bucket_keeps_splits_balanced_and_few():
                 # the longest split of the replayed geometry is within 7 % of the planner's
                 assert q <= 1.07 * sbs + 64
     assert len(widths) <= 5 * 4, len(widths)
+
+
+def test_tiny_batch_projection_policy():
+    """kernels/linear.py: when may a projection consume the previous projection's slabs / the attention partials itself?
+    (pure host logic: shapes, packed twin, K-chunk that fits LDS; the layer additionally limits the batch to 2)."""
+    import torch
+    import importlib
+    L = importlib.import_module("swiftllm_amd.worker.kernels.linear")
+    assert L._TINY_POLICY_M <= L._TINY_MAX_M == 4
+
+    def weight(n, k, packed=True):
+        w = torch.empty(n, k, dtype=torch.bfloat16)
+        if packed:
+            w._swl_packed = torch.empty(0)
+        return w
+
+    def partials(m, k, dtype=torch.bfloat16):
+        return L.SplitKPartials(torch.empty(0), 8, m, k, dtype)
+
+    wq, wug = weight(6144, 4096), weight(28672, 4096)
+    assert L.tiny_from_splitk_ok(partials(1, 4096), wq) and L.tiny_from_splitk_ok(partials(4, 4096), wq)
+    assert not L.tiny_from_splitk_ok(partials(5, 4096), wq)                        # more than 4 tokens
+    assert not L.tiny_from_splitk_ok(partials(1, 4096), weight(6144, 4096, packed=False))
+    assert not L.tiny_from_splitk_ok(partials(1, 4096, torch.float16), wq)         # dtype mismatch
+    assert not L.tiny_from_splitk_ok(torch.empty(1, 4096), wq)                     # a tensor, not slabs
+    assert L.tiny_from_splitk_ok(partials(2, 4096), wug, silu=True)
+    assert not L.tiny_from_splitk_ok(partials(2, 8192), weight(28672, 8192), silu=True)   # whole K must fit LDS
+    assert L.attn_partials_ok(1, 32, 128, weight(4096, 4096)) and not L.attn_partials_ok(5, 32, 128, weight(4096, 4096))
+    assert not L.attn_partials_ok(1, 32, 128, weight(4096, 2048))                  # K != H * D
+    assert not L.attn_partials_ok(1, 4, 32, weight(128, 128))                      # o_proj not split over K: nothing to fuse

@@ -128,20 +128,41 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(PrefillParams p) {
     const int srow = tid / CPR;
     const int sc = tid % CPR;
     vec8_t<T> kst[NPASS], vst[NPASS];
+    // Row pointers of this thread's staging passes, advanced by one tile per fetch (tiles are fetched in order). r01
+    // recomputed `(start + key) * token_stride` per load: 92 VALU instructions per tile, a third of them quarter-rate
+    // 32-bit multiplies of the 64-bit product — ~700 cycles beside the 1024 cycles of the tile's 32 MFMAs, the "staging
+    // cost" that neither fewer barriers, more occupancy nor a longer fetch distance could touch (profiles/r02n).
+    const T *kp[NPASS], *vp[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int64_t tok = static_cast<int64_t>(start) + srow + ps * RPP;
+        kp[ps] = kg + tok * p.k_tok_stride + sc * 8;
+        vp[ps] = vg + tok * p.v_tok_stride + sc * 8;
+    }
+    const int64_t kstep = static_cast<int64_t>(kBK) * p.k_tok_stride, vstep = static_cast<int64_t>(kBK) * p.v_tok_stride;
     auto fetch_tile = [&](int key0) {
+        if (key0 + kBK <= len) { // (workgroup-uniform) every row of the tile exists: plain loads
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                kst[ps] = load8(kp[ps]);
+                vst[ps] = load8(vp[ps]);
+            }
+        } else {                  // the sequence ends inside this tile: rows past it are zeros, their pointers unused
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                vec8_t<T> kt = vec8_t<T>{}, vt = vec8_t<T>{};
+                if (key0 + srow + ps * RPP < len) {
+                    kt = load8(kp[ps]);
+                    vt = load8(vp[ps]);
+                }
+                kst[ps] = kt;
+                vst[ps] = vt;
+            }
+        }
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
-            const int key = key0 + srow + ps * RPP;
-            const bool ok = key < len;
-            const int64_t tok = static_cast<int64_t>(start) + (ok ? key : 0);
-            vec8_t<T> kt = load8(kg + tok * p.k_tok_stride + sc * 8);
-            vec8_t<T> vt = load8(vg + tok * p.v_tok_stride + sc * 8);
-            if (!ok) {
-                kt = vec8_t<T>{};
-                vt = vec8_t<T>{};
-            }
-            kst[ps] = kt;
-            vst[ps] = vt;
+            kp[ps] += kstep;
+            vp[ps] += vstep;
         }
     };
     auto commit_tile = [&]() {

@@ -5,6 +5,14 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+With --gpus N and no launcher environment (WORLD_SIZE unset) the script starts the N ranks itself, one process per GPU
+(HIP_VISIBLE_DEVICES=i), and rank 0 prints the line.
+
+The KV pool is the real one: `LlamaModel.profile_num_blocks()` at gpu_mem_utilization 0.97 (~125 k blocks = 262 GB for
+Llama-3-8B on a 288 GB MI355X; `config.kv_pool_blocks` / `kv_pool_gb`), and the run's sequences live in the HIGHEST
+block ids of it (filler sequences hold the low ones): every pool offset the timed kernels form is far beyond 2^31
+elements.
+
 Workload (BASELINE.json configs[2]): Llama-3-8B, bf16, random-init weights, batch 32 per GPU, 1024-token synthetic
 prompts, 128 generated tokens. One "step" = one decode forward of the whole batch (`LlamaModel.forward`, the hot
 path) with everything resident in HBM. The K timed steps always sit in the MIDDLE of the 128-token generation —
@@ -24,7 +32,11 @@ Extra objects on the JSON line:
                   roofline_up_gate_gemm). The attention entry is swl_paged_attn_decode_qkv fed by real split-K slabs —
                   the variant the step runs.
   step_roofline   the whole decode step against HBM: (weights + KV read + KV write) / step time.
-  eager           the same K steps with hipGraph replay off (the product default), next to the replayed `value`.
+  eager           the same K steps with hipGraph replay off (--no-hip-graph; replay is the product default since r03).
+  reference_triton rank 0, N=1 only: the REFERENCE's own LlamaModel.forward (its Triton kernels compiled for gfx950 +
+                  F.linear; oracle/ref_triton.py on the staged oracle/_ref copy) timed in a child process on the same
+                  box, same batch, same timed contexts, after this process has released the GPU. Skipped when
+                  oracle/_ref is absent.
   configs1_batch1 / configs3_llama2_7b_4x16k   (rank 0, N=1) short driver-measured runs of BASELINE configs[1]
                   and configs[3] (KV pre-filled, no 16k prefill).
   cpu_baseline    rank 0, N=1 only: the CPU oracle's forward (oracle/ref_model.py — the reference has no CPU path
@@ -60,13 +72,16 @@ def parse_args():
     ap.add_argument("--no-fuse-qkv", dest="fuse_qkv", action="store_false")
     ap.add_argument("--no-skinny-gemm", dest="skinny_gemm", action="store_false")
     ap.add_argument("--no-splitk-fusion", dest="splitk_fusion", action="store_false")
-    ap.add_argument("--layer-fusion", dest="layer_fusion", action="store_true",
-                    help="fold norm/rotary/residual hand-offs into the GEMMs (experimental, slower: DESIGN.md §4.4)")
     ap.add_argument("--no-packed-weights", dest="packed_weights", action="store_false")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[1] / configs[3] / eager side runs")
     ap.add_argument("--skip-prefill", action="store_true", help="fill the KV pool directly instead of running the prompt")
     ap.add_argument("--kernel-iters", type=int, default=256)
+    ap.add_argument("--kv-blocks", type=int, default=0,
+                    help="KV pool size in blocks; 0 = profile_num_blocks() at gpu_mem_utilization 0.97 (the product's sizing)")
+    ap.add_argument("--kv-placement", default="top", choices=["top", "bottom"],
+                    help="top: filler sequences occupy the low block ids, the run's sequences get the highest ones")
+    ap.add_argument("--no-reference", action="store_true", help="skip the reference-Triton child run")
     return ap.parse_args()
 
 
@@ -98,19 +113,25 @@ def ensure_positions(cfg, needed):
     return cfg
 
 
-def build_model(args, cfg, num_blocks, batch, max_len, hip_graph):
+FILLER_BLOCKS_PER_SEQ = 8192    # block-table columns: a filler sequence holds up to this many blocks
+
+
+def build_model(args, cfg, min_blocks, batch, max_len, hip_graph):
+    """The model with its KV pool. Pool size: --kv-blocks, else what the product's own sizing gives on this GPU
+    (LlamaModel.profile_num_blocks at gpu_mem_utilization 0.97: reference model.py:94-131), never less than the run
+    needs. With --kv-placement top, filler sequences (ids batch, batch+1, ...) take the low block ids so that the run's
+    sequences are allocated — lowest free id first, as always — at the very top of the pool."""
     import torch
     from swiftllm_amd import EngineConfig, LlamaModel
     path = tempfile.mkdtemp(prefix="swl_bench_")
     with open(os.path.join(path, "config.json"), "w", encoding="utf-8") as f:
         json.dump(cfg, f)
     ec = EngineConfig(model_path=path, use_dummy=True, block_size=16, gpu_mem_utilization=0.97,
-                      num_cpu_blocks=0, max_seqs_in_block_table=max(64, batch),
-                      max_blocks_per_seq=max(256, max_len // 16 + 8),
+                      num_cpu_blocks=0, max_seqs_in_block_table=max(64, batch) + 64,
+                      max_blocks_per_seq=max(FILLER_BLOCKS_PER_SEQ, max_len // 16 + 8),
                       max_batch_size=batch, max_tokens_in_batch=batch * min(max_len, 8192),
                       dtype=args.dtype, fuse_qkv=args.fuse_qkv, use_hip_graph=hip_graph,
                       use_skinny_gemm=args.skinny_gemm, fuse_splitk_consumers=args.splitk_fusion,
-                      fuse_decode_layer=getattr(args, "layer_fusion", False),
                       pack_decode_weights=getattr(args, "packed_weights", True))
     model = LlamaModel(ec)
     model.load_weights()
@@ -128,11 +149,39 @@ def build_model(args, cfg, num_blocks, batch, max_len, hip_graph):
             else:
                 t.normal_(0.0, 0.02, generator=g)
     model.repack_decode_weights()       # the packed decode copies follow the re-initialised weights
+    num_blocks = int(getattr(args, "kv_blocks", 0) or 0)
+    if num_blocks <= 0:
+        num_blocks = model.profile_num_blocks()
+    num_blocks = max(num_blocks, min_blocks)
     model.init_kvcache_and_swap(num_blocks)
     with torch.inference_mode():        # positions the bench skips over must hold data, not zeros (DVFS: §5.4 rule 25)
-        model.k_cache.normal_(0.0, 1.0, generator=g)
-        model.v_cache.normal_(0.0, 1.0, generator=g)
+        chunk = 4096                    # (in slices: one 130 GB normal_() would need a 64-bit element counter per launch)
+        for b0 in range(0, num_blocks, chunk):
+            model.k_cache[b0:b0 + chunk].normal_(0.0, 1.0, generator=g)
+            model.v_cache[b0:b0 + chunk].normal_(0.0, 1.0, generator=g)
+    model.bench_filler_ids = []
+    if getattr(args, "kv_placement", "top") == "top":
+        spare = num_blocks - min_blocks
+        sid = max(64, batch)
+        while spare > 0 and sid < ec.max_seqs_in_block_table:
+            n = min(spare, FILLER_BLOCKS_PER_SEQ)
+            model.gpu_block_manager.allocate_blocks_for_seqs([sid], [n * 16])
+            model.bench_filler_ids.append(sid)
+            spare -= n
+            sid += 1
     return model
+
+
+def pool_report(model):
+    """What the pool is and where the run's blocks sit in it (for the JSON line)."""
+    host = model.gpu_block_manager.host
+    used = [b for sid, blocks in host.seq_blocks.items() if sid not in set(model.bench_filler_ids) for b in blocks]
+    block_elems = model.k_cache[0].numel()
+    return {"kv_pool_blocks": int(model.num_blocks),
+            "kv_pool_gb": round(2 * model.k_cache.numel() * model.k_cache.element_size() / 1e9, 1),
+            "kv_filler_blocks": int(sum(len(host.seq_blocks.get(s, ())) for s in model.bench_filler_ids)),
+            "kv_run_block_ids": [int(min(used)), int(max(used))] if used else None,
+            "kv_run_min_element_offset": int(min(used)) * block_elems if used else None}
 
 
 def timed(fn):
@@ -326,23 +375,29 @@ def gemm_roofline(model, batch, iters):
 
 
 def cpu_baseline(cfg, batch, context, dtype):
-    """The CPU oracle (a port: the reference has no CPU forward) on the host cores: same architecture
-    and batch, truncated to 2 of the layers, short context, a couple of decode steps (~10-30 s incl.
-    building the random weights); per-layer and head costs are timed separately and recombined for
-    the full depth. This is the ONLY part of bench.py that touches oracle/."""
+    """The CPU oracle (a port: the reference has no CPU forward) on the host cores: ONE transformer layer of the same
+    architecture at the bench's batch and MEAN TIMED CONTEXT — KV pool filled directly with N(0,1) data, no prompt
+    pass — a few decode steps; the layer cost (attention over the real context included) is timed apart from
+    embedding + lm_head and recombined for the full depth. ~10-30 s including building the random weights. This is the
+    ONLY part of bench.py that touches oracle/."""
     import torch
     from oracle import eager_ops, synth
     from oracle.ref_model import RefLlamaModel
     from swiftllm_amd import EngineConfig, LlamaModelConfig
-    small = dict(cfg, num_hidden_layers=2)
+    small = dict(cfg, num_hidden_layers=1)
     tdtype = torch.bfloat16 if dtype == "bfloat16" else torch.float16
     sd = synth.make_state_dict(small, seed=0, dtype=tdtype)
+    steps = 3
+    blocks_per_seq = (context + steps) // 16 + 2
     ec = EngineConfig(model_path="", use_dummy=True, block_size=16, gpu_mem_utilization=0.9,
-                      num_cpu_blocks=0, max_seqs_in_block_table=batch, max_blocks_per_seq=context // 16 + 4,
-                      max_batch_size=batch, max_tokens_in_batch=batch * context)
+                      num_cpu_blocks=0, max_seqs_in_block_table=batch, max_blocks_per_seq=blocks_per_seq + 2,
+                      max_batch_size=batch, max_tokens_in_batch=batch * 16)
     eager_ops.linear = lambda a, w: torch.nn.functional.linear(a, w)    # native 16-bit CPU GEMM
     ref = RefLlamaModel(LlamaModelConfig(small), ec, sd, tdtype)
-    ref.init_kvcache_and_swap(batch * (context // 16 + 2))
+    ref.init_kvcache_and_swap(batch * blocks_per_seq)
+    g = torch.Generator().manual_seed(1)
+    ref.k_cache.copy_(torch.randn(ref.k_cache.shape, generator=g).to(tdtype))
+    ref.v_cache.copy_(torch.randn(ref.v_cache.shape, generator=g).to(tdtype))
     layer_s = [0.0]
     orig_layer = ref._layer
 
@@ -352,24 +407,49 @@ def cpu_baseline(cfg, batch, context, dtype):
         layer_s[0] += time.perf_counter() - t0
         return r
     ref._layer = timed_layer
-    g = torch.Generator().manual_seed(1)
-    prompts = [torch.randint(0, cfg["vocab_size"], (context,), generator=g).tolist() for _ in range(batch)]
-    toks = ref.forward(prompts, list(range(batch)), [])
-    steps, total, layers = 2, 0.0, 0.0
-    for s in range(steps):
+    toks = torch.randint(0, cfg["vocab_size"], (batch,), generator=g).tolist()
+    first = context - steps // 2
+    total, layers = 0.0, 0.0
+    for s in range(-1, steps):      # step -1: untimed warm-up (allocates the blocks, touches the weights)
         layer_s[0] = 0.0
         t0 = time.perf_counter()
-        toks = ref.forward([[t] for t in toks], list(range(batch)), [context + 1 + s] * batch)
-        total += time.perf_counter() - t0
-        layers += layer_s[0]
-    per_layer = layers / steps / 2
+        toks = ref.forward([[t] for t in toks], list(range(batch)), [first + s] * batch)
+        if s >= 0:
+            total += time.perf_counter() - t0
+            layers += layer_s[0]
+    per_layer = layers / steps
     rest = (total - layers) / steps
     full_step = per_layer * cfg["num_hidden_layers"] + rest
     return dict(value=round(batch / full_step, 3), unit="tokens/s", cores=torch.get_num_threads(), kind="port",
-                sample=(f"oracle/ref_model.py decode step, batch {batch}, context {context}, 2 of "
+                sample=(f"oracle/ref_model.py decode step, batch {batch}, contexts {first}..{first + steps - 1} (KV pool "
+                        f"filled directly, paged attention over the full context included), 1 of "
                         f"{cfg['num_hidden_layers']} layers timed ({per_layer * 1e3:.1f} ms/layer) + embedding/"
                         f"lm_head ({rest * 1e3:.1f} ms), recombined for {cfg['num_hidden_layers']} layers; "
                         f"{steps} steps, native 16-bit CPU GEMM"))
+
+
+def reference_triton_leg(batch, first_ctx, steps, warmup):
+    """The reference's own data plane on this GPU (oracle/ref_triton.py: its LlamaModel.forward, its Triton kernels
+    compiled by Triton's gfx950 backend, F.linear; fp16 — the only precision the reference has) timed in a child
+    process at the SAME batch and the SAME timed contexts as `value`. Runs after this process has released its model
+    (the reference builds its own 16 GB of weights). None when oracle/_ref is not staged or the child fails: a side
+    measurement must never take the bench line down."""
+    import subprocess
+    if not os.path.isfile(os.path.join(ROOT, "oracle", "_ref", "swiftllm", "worker", "model.py")):
+        return None
+    cmd = [sys.executable, "-m", "oracle.ref_triton", "bench", "--config", "c2", "--batch", str(batch),
+           "--first-context", str(first_ctx), "--steps", str(steps), "--warmup", str(warmup)]
+    env = dict(os.environ)
+    env.pop("TRITON_INTERPRET", None)
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600, check=True)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        return dict(value=d["decode_tok_s"], unit="tokens/s", ms_per_step=d["ms_per_step"], dtype=d["dtype"],
+                    contexts=[d["context_first"], d["context_last"]], steps=d["steps"], warmup=d["warmup"],
+                    path=d["path"], how="child process: " + " ".join(cmd[1:]))
+    except Exception as e:     # noqa: BLE001
+        print(f"[bench] reference Triton leg failed ({type(e).__name__}: {e})", file=sys.stderr)
+        return None
 
 
 def side_run(args, model_name, batch, context, steps, warmup, label, model=None):
@@ -426,6 +506,9 @@ def side_run_fresh_process(args, label):
 def main():
     args = parse_args()
     from swiftllm_amd import dp
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the N ranks ourselves, one process per GPU; rank 0 prints the JSON line
+        raise SystemExit(dp.spawn_local_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     rank, local_rank, world = dp.env_rank_world()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -451,6 +534,7 @@ def main():
     num_blocks = int(B * blocks_per_seq * 1.25) + 8
     model = build_model(args, cfg, num_blocks, B, last_needed + 2, not args.no_hip_graph)
     e = model.dtype.itemsize
+    pool = None
 
     # every rank serves its own shard of the requests: `batch` sequences per GPU
     g = torch.Generator().manual_seed(1 + rank)
@@ -471,6 +555,7 @@ def main():
     # ---- decode: W warm-up steps, then exactly K timed steps, centred in the generation --------------------------
     run.jump_to(max(S + 1, first_timed - Wm))
     local_s, first_ctx, last_ctx = run.timed_steps(Wm, K, dp.barrier)
+    pool = pool_report(model)
     units, max_s = dp.reduce_job(B * K, local_s)
     graphs = len(getattr(model, "_decode_graphs", {}))
 
@@ -493,7 +578,7 @@ def main():
                    "parallelism": f"request-sharded dp{world} (independent replicas, no collective)",
                    "hip_graph": not args.no_hip_graph, "fuse_qkv": args.fuse_qkv,
                    "skinny_gemm": args.skinny_gemm, "packed_decode_weights": getattr(args, "packed_weights", True),
-                   "kv_blocks": num_blocks, "decode_graphs_captured": graphs,
+                   **pool, "decode_graphs_captured": graphs,
                    "cpu_affinity_cores": len(pinned) if pinned else None},
         "step_roofline": step_roofline(cfg, e, B, mean_ctx, ms_per_step),
     }
@@ -510,7 +595,7 @@ def main():
         if gemm is not None:
             result["roofline_up_gate_gemm"] = gemm
     if world == 1 and not args.no_extras:
-        # the same K steps with hipGraph replay off (EngineConfig's default), same contexts
+        # the same K steps with hipGraph replay off (one HIP launch per kernel from Python), same contexts
         if not args.no_hip_graph:
             model.engine_config.use_hip_graph = False
             run.release()
@@ -533,8 +618,12 @@ def main():
         label = "BASELINE.json configs[3]: Llama-2-7B dims, batch 4, 16k context"
         result["configs3_llama2_7b_4x16k"] = (side_run_fresh_process(args, label)
                                               or side_run(args, "llama2-7b", 4, 16384 + 32, 24, 4, label))
+    if world == 1 and not args.no_extras and not args.no_reference and args.model == "llama3-8b":
+        ref = reference_triton_leg(B, first_ctx, K, Wm)
+        if ref is not None:
+            result["reference_triton"] = ref
     if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(cfg, B, 16, args.dtype)
+        result["cpu_baseline"] = cpu_baseline(cfg, B, int(round(mean_ctx)), args.dtype)
     print(json.dumps(result), flush=True)
 
 

@@ -270,37 +270,6 @@ int swl_gemm_packed_mid_partial(float *slabs, size_t slabs_bytes, const void *x,
                                 int32_t N, int32_t K, int64_t x_row_stride, int32_t k_splits, int32_t dtype,
                                 swl_stream_t stream);
 
-/* ---- Fused decode layer: the latency-bound hand-offs between the projections folded into the GEMMs --------
- * (reference: transformer_layer.py:31-130 runs fused_add_rmsnorm / rotary / store_kvcache as separate
- * kernels between the linears). Split-K workgroups that share an output tile count themselves in; the last one
- * to arrive sums the tile's slabs in slab order and applies the consumer. `counters` is int64[counters_len >=
- * N/128], zero before the first launch (every launch leaves it zero again). M <= 32, N % 128 == 0, K % 128 == 0.
- *
- * swl_gemm_skinny_add_residual: residual[M, N] += round(x . W^T); ssq_out[N/128][32] <- per-128-column-tile
- *   sums of squares of the updated residual rows   (o_proj / down_proj + the add half of rmsnorm.py:39-65)
- * swl_gemm_skinny_norm_silu_gate: out[M, I] = up * silu(gate) of rmsnorm(x) . [up ; gate]^T, where x is the
- *   un-normalised residual stream, ssq_in[ssq_parts][32] its per-tile row sums of squares, K <= 4096
- * swl_gemm_skinny_qkv_rope_store: fused qkv projection (+ attention RMSNorm on the fly when ssq_in != NULL)
- *   whose epilogue rotates q/k (rotary_emb.py:7-42), writes q_out[M, H, D] and stores k/v into the paged
- *   pools (kvcache_mgmt.py:50-79). head_dim in {32, 64, 128}. */
-int swl_gemm_skinny_add_residual(void *residual, float *ssq_out, const void *x, const void *w, float *slabs,
-                                 size_t slabs_bytes, int64_t *counters, int32_t counters_len, int32_t M,
-                                 int32_t N, int32_t K, int64_t x_row_stride, int32_t dtype, swl_stream_t stream);
-int swl_gemm_skinny_norm_silu_gate(void *out, const void *x, const float *ssq_in, int32_t ssq_parts,
-                                   const void *norm_w, float eps, const void *w_up_gate, int32_t M, int32_t I,
-                                   int32_t K, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype,
-                                   swl_stream_t stream);
-int swl_gemm_skinny_qkv_rope_store(void *q_out, const void *x, const float *ssq_in, int32_t ssq_parts,
-                                   const void *norm_w, float eps, const void *w_qkv, float *slabs,
-                                   size_t slabs_bytes, int64_t *counters, int32_t counters_len,
-                                   const void *cos_table, const void *sin_table, const int32_t *pos_idx,
-                                   void *k_cache, void *v_cache, const int32_t *block_table,
-                                   const int32_t *seq_ids, const int32_t *seq_lens, int32_t num_decoding_seqs,
-                                   int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, int32_t K,
-                                   int32_t cur_layer, int32_t num_layers, int32_t block_size,
-                                   int32_t max_blocks_per_seq, int64_t q_tok_stride, int64_t x_row_stride,
-                                   int32_t dtype, swl_stream_t stream);
-
 /* Split-K without the reduce launch: the GEMM stops at its fp32 partial slabs [k_splits][M][N] and a FUSED
  * CONSUMER adds them (slab order, one rounding — bit-identical to swl_gemm_skinny's own reduce):
  *   o_proj / down_proj  -> swl_splitk_fused_add_rmsnorm      (reference: rmsnorm.py:39-89)
@@ -363,28 +332,6 @@ int swl_paged_attn_decode_qkv_rs(void *o, const float *qkv_slabs, int32_t k_spli
                                  int32_t num_kv_heads, int32_t head_dim, int32_t num_layers, int32_t block_size,
                                  int32_t cur_layer, int32_t max_blocks_per_seq, int32_t seq_block_size,
                                  int32_t num_seq_blocks, int64_t o_tok_stride, int32_t dtype, swl_stream_t stream);
-
-/* ---- decode projections with K split inside the workgroup (csrc/gemm_wgk.hip) ------------------------------------
- * The hidden-by-hidden projections of a decode layer (reference linear.py:3-12 at transformer_layer.py:54-56 and :117)
- * for M <= 32 tokens on a packed weight (swl_gemm_pack_weight): one workgroup owns 32 rows of W for all of K, its 8
- * waves split K and add their accumulators through LDS in wave order — the bits of the 8-slab split-K sum — so the
- * projection needs no slab workspace and no consumer launch. N % 32 == 0, K % 1024 == 0 (swl_gemm_wgk_supported).
- *   swl_gemm_wgk: out[M, N] = round(rstd[m] * (x . W^T)) in the storage dtype, or unrounded fp32 when out_fp32 != 0 (the
- *     single "slab" swl_paged_attn_decode_qkv takes with k_splits = 1). row_ssq == NULL: rstd = 1; else the deferred
- *     RMSNorm scale rstd[m] = 1/sqrt(sum_{p < ssq_parts} row_ssq[p * ssq_stride + m] / K + eps), ssq_parts <= 16
- *     (swl_splitk_add_scale's output: ssq_stride = M).
- *   swl_gemm_wgk_add_scale: o_proj + the element-wise half of the FFN norm (transformer_layer.py:117-120, rmsnorm.py:
- *     67-89): residual[m, :] += round(x . W^T) (stored rounded, as the reference stores it); x_scaled = round(residual *
- *     norm_w); ssq_out[N/32][32] = per-32-column sums of squares of the updated residual rows (rows >= M unwritten) —
- *     the same arithmetic as swl_gemm_skinny_packed_partial (k_splits = 8) + swl_splitk_add_scale, bit for bit on
- *     residual and x_scaled. Consumer: swl_gemm_skinny_packed_silu_gate_rs with ssq_parts = N/32, ssq_stride = 32. */
-int swl_gemm_wgk_supported(int32_t M, int32_t N, int32_t K);
-int swl_gemm_wgk(void *out, int32_t out_fp32, const void *x, const void *w_packed, const float *row_ssq,
-                 int32_t ssq_parts, int32_t ssq_stride, float eps, int32_t M, int32_t N, int32_t K,
-                 int64_t x_row_stride, int64_t out_row_stride, int32_t dtype, swl_stream_t stream);
-int swl_gemm_wgk_add_scale(void *x_scaled, void *residual, float *ssq_out, const void *norm_w, const void *x,
-                           const void *w_packed, int32_t M, int32_t N, int32_t K, int64_t x_row_stride, int32_t dtype,
-                           swl_stream_t stream);
 
 /* ---- decode projections for very small batches that consume the previous projection's slabs (csrc/gemm_tiny.hip) ----
  * M <= swl_gemm_tiny_max_tokens() (4). At batch 1 the two split-K consumers of a decode layer (swl_splitk_add_scale:

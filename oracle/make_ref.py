@@ -8,6 +8,15 @@ exactly like our own built .so files). This script copies the reference's `swift
 Triton kernels with Triton's gfx950 backend on the box: the "Tier 2" oracle of SURVEY.md §8c and the
 "reference Triton-path tokens/s" side of the north-star comparison. Nothing under oracle/_ref/ is ever
 committed, and nothing in swiftllm_amd/ ever imports it.
+
+Two more things are staged next to it:
+  * `oracle/_ref/bf16/swiftllm/` — the same files with every `float16` token replaced by `bfloat16` (torch.float16
+    -> torch.bfloat16, tl.float16 -> tl.bfloat16; SURVEY.md H6: the reference hard-codes fp16 at model.py:70,147-148,
+    224-225 and in four kernels). The headline dtype is bf16 and the reference has no bf16 path: this mechanical patch
+    is the closest thing to "the reference in bf16" (its decode-attention scores then round to bf16 too). The manifest
+    records which files changed and how many substitutions each took.
+  * `oracle/_ref/examples/` — the reference's own examples/offline.py and examples/online.py, byte for byte, for the
+    drop-in acceptance test (tests/test_gpu_reference_examples.py) that runs them against THIS repo's `swiftllm` alias.
 """
 import hashlib
 import json
@@ -40,10 +49,40 @@ def stage(verbose: bool = True) -> str:
             shutil.copyfile(s, d)
             with open(s, "rb") as f:
                 manifest[rel] = hashlib.sha256(f.read()).hexdigest()
+    # bf16-patched twin
+    patched = {}
+    bf16_root = os.path.join(DEST, "bf16")
+    if os.path.isdir(bf16_root):
+        shutil.rmtree(bf16_root)
+    for rel in manifest:
+        with open(os.path.join(REFERENCE, rel), encoding="utf-8") as f:
+            text = f.read()
+        n = text.count("float16")
+        d = os.path.join(bf16_root, rel)
+        os.makedirs(os.path.dirname(d), exist_ok=True)
+        with open(d, "w", encoding="utf-8") as f:
+            f.write(text.replace("float16", "bfloat16"))
+        if n:
+            patched[rel] = n
+    # the reference's own example scripts, untouched
+    examples = {}
+    ex_dst = os.path.join(DEST, "examples")
+    if os.path.isdir(ex_dst):
+        shutil.rmtree(ex_dst)
+    os.makedirs(ex_dst)
+    for name in ("offline.py", "online.py"):
+        s = os.path.join(REFERENCE, "examples", name)
+        if os.path.isfile(s):
+            shutil.copyfile(s, os.path.join(ex_dst, name))
+            with open(s, "rb") as f:
+                examples["examples/" + name] = hashlib.sha256(f.read()).hexdigest()
     with open(os.path.join(DEST, "MANIFEST.json"), "w", encoding="utf-8") as f:
-        json.dump({"staged_from": REFERENCE, "files": manifest}, f, indent=1, sort_keys=True)
+        json.dump({"staged_from": REFERENCE, "files": manifest, "bf16_patched_substitutions": patched,
+                   "examples": examples}, f, indent=1, sort_keys=True)
     if verbose:
-        print(f"[oracle.make_ref] staged {len(manifest)} reference files under {DEST}")
+        print(f"[oracle.make_ref] staged {len(manifest)} reference files under {DEST} "
+              f"(+ bf16-patched twin: {sum(patched.values())} substitutions in {len(patched)} files; "
+              f"{len(examples)} example scripts)")
     return DEST
 
 

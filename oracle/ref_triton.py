@@ -45,8 +45,12 @@ def staged_available() -> bool:
     return os.path.isfile(os.path.join(STAGED, "swiftllm", "worker", "model.py"))
 
 
-def load_reference():
-    """Import the staged reference as `swiftllm` (compiled Triton: TRITON_INTERPRET must be unset)."""
+def load_reference(dtype: str = "float16"):
+    """Import the staged reference as `swiftllm` (compiled Triton: TRITON_INTERPRET must be unset). dtype "bfloat16"
+    imports the mechanically patched twin oracle/_ref/bf16 (oracle/make_ref.py: float16 -> bfloat16 everywhere)."""
+    global STAGED
+    if dtype == "bfloat16":
+        STAGED = os.path.join(HERE, "_ref", "bf16")
     if not staged_available():
         raise SystemExit(f"{STAGED}/swiftllm is absent: run `python -m oracle.make_ref` in the build container")
     if os.environ.get("TRITON_INTERPRET"):
@@ -140,9 +144,13 @@ def cmd_bench(args):
     """Decode tokens/s (and one prefill) of the reference's forward at a BASELINE config: its Triton kernels +
     F.linear (hipBLASLt), fp16, dummy weights re-initialised to N(0, 0.02^2) like bench.py."""
     import torch
-    swiftllm = load_reference()
+    swiftllm = load_reference(args.dtype)
     name, batch, ctx, label = BENCH_CONFIGS[args.config]
     steps, warmup = args.steps, args.warmup
+    if args.batch > 0:
+        batch = args.batch
+    if args.first_context > 0:      # context (incl. the new token) of the first TIMED step
+        ctx = args.first_context - warmup
     cfg = _config_dict(name, ctx + steps + warmup + 2)
     path = tempfile.mkdtemp(prefix="ref_bench_")
     with open(os.path.join(path, "config.json"), "w", encoding="utf-8") as f:
@@ -163,7 +171,8 @@ def cmd_bench(args):
                 t.normal_(0.0, 0.02, generator=g)
     gp = torch.Generator().manual_seed(1)
     seq_ids = list(range(batch))
-    out = dict(config=args.config, workload=label, model=name, batch=batch, dtype="f16",
+    out = dict(config=args.config, workload=label, model=name, batch=batch,
+               dtype="f16" if args.dtype == "float16" else "bf16 (float16 -> bfloat16 patched reference)",
                path="reference swiftllm LlamaModel.forward: its Triton kernels (triton gfx950 backend) + F.linear")
     if args.prefill_len > 0:
         plen = args.prefill_len
@@ -201,15 +210,17 @@ def cmd_forward(args):
     """in.pt: dict(config=HF config dict, model_path=dir with safetensors, num_blocks, max_len,
     steps=[dict(input_ids, seq_ids, dec_lens)]). out.pt: per step tokens + pre-argmax logits (fp32, CPU)."""
     import torch
-    swiftllm = load_reference()
-    from swiftllm.worker.layers import post_layer as post_mod
     job = torch.load(args.inp)
+    swiftllm = load_reference(job.get("dtype", "float16"))
+    from swiftllm.worker.layers import post_layer as post_mod
     logits_log = []
     orig_linear = post_mod.linear
 
+    keep = job.get("logits", "fp32")     # "fp32" | "storage" (exact, half the bytes) | "none"
+
     def tapped_linear(a, w):
         r = orig_linear(a, w)
-        logits_log.append(r.float().cpu())
+        logits_log.append(None if keep == "none" else (r.cpu() if keep == "storage" else r.float().cpu()))
         return r
     post_mod.linear = tapped_linear     # the only linear() in post_layer.py is lm_head (:38)
     batch = max(len(s["seq_ids"]) for s in job["steps"])
@@ -307,6 +318,11 @@ def main():
     b.add_argument("--steps", type=int, default=20)
     b.add_argument("--warmup", type=int, default=5)
     b.add_argument("--prefill-len", type=int, default=0)
+    b.add_argument("--dtype", default="float16", choices=["float16", "bfloat16"],
+                   help="bfloat16 = the mechanically patched twin under oracle/_ref/bf16")
+    b.add_argument("--batch", type=int, default=0, help="override the config's batch size")
+    b.add_argument("--first-context", type=int, default=0,
+                   help="context (including the new token) of the first timed step (default: the config's + warmup)")
     for name in ("forward", "ops"):
         p = sub.add_parser(name)
         p.add_argument("inp")

@@ -66,11 +66,6 @@ SIGNATURES = {
     "swl_gemm_skinny_partial": [_P, ctypes.c_size_t, _P, _P, _I32, _I32, _I32, _I64, _I32, _I32, _P],
     "swl_splitk_reduce": [_P, _P, _I32, _I32, _I32, _I64, _I32, _P],
     "swl_gemm_skinny_silu_gate": [_P, _P, _P, _I32, _I32, _I32, _I64, _I64, _I32, _P],
-    "swl_gemm_skinny_add_residual": [_P, _P, _P, _P, _P, ctypes.c_size_t, _P, _I32, _I32, _I32, _I32, _I64, _I32, _P],
-    "swl_gemm_skinny_norm_silu_gate": [_P, _P, _P, _I32, _P, _F32, _P, _I32, _I32, _I32, _I64, _I64, _I32, _P],
-    "swl_gemm_skinny_qkv_rope_store": [_P, _P, _P, _I32, _P, _F32, _P, _P, ctypes.c_size_t, _P, _I32, _P, _P, _P,
-                                       _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32,
-                                       _I64, _I64, _I32, _P],
     "swl_splitk_fused_add_rmsnorm": [_P, _P, _P, _F32, _P, _I32, _I64, _I32, _I32, _P],
     "swl_splitk_add_scale": [_P, _P, _P, _P, _I32, _P, _I64, _I32, _I32, _P],
     "swl_gemm_skinny_packed_silu_gate_rs": [_P, _P, _P, _P, _I32, _F32, _I32, _I32, _I32, _I64, _I64, _I32, _P],
@@ -78,8 +73,6 @@ SIGNATURES = {
                                      _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I32, _P],
     "swl_splitk_rotary_store_kv_decode": [_P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32,
                                           _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _P],
-    "swl_gemm_wgk": [_P, _I32, _P, _P, _P, _I32, _I32, _F32, _I32, _I32, _I32, _I64, _I64, _I32, _P],
-    "swl_gemm_wgk_add_scale": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I64, _I32, _P],
     "swl_paged_attn_decode_qkv_rs_partials": [_P, _P, _I32, _P, _I32, _I32, _F32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F32,
                                               _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I32, _P],
     "swl_gemm_tiny_partial_from_attn": [_P, ctypes.c_size_t, _I32, _P, _P, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _P],
@@ -96,7 +89,6 @@ _SPECIAL = {
     "swl_gemm_skinny_choose_splits": ([_I32, _I32], _I32),
     "swl_gemm_skinny_packed_choose_splits": ([_I32, _I32], _I32),
     "swl_gemm_packed_mid_choose_splits": ([_I32, _I32, _I32], _I32),
-    "swl_gemm_wgk_supported": ([_I32, _I32, _I32], _I32),
     "swl_gemm_tiny_max_tokens": ([], _I32),
 }
 

@@ -11,6 +11,7 @@ import os
 import shutil
 import subprocess
 import sys
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
@@ -24,7 +25,6 @@ SOURCES = [
     "block_table.hip",
     "swap_blocks.hip",
     "gemm_skinny.hip",
-    "gemm_wgk.hip",
     "gemm_tiny.hip",
     "argmax.hip",
 ]
@@ -52,12 +52,11 @@ def _newer(target: str, deps) -> bool:
 
 
 def build(force: bool = False, jobs: int = 0, verbose: bool = True, tag: str = "", defines=(), swap=None) -> str:
-    """Build the library. `tag` + `defines` (-D macros) build an EXPERIMENT variant next to it
-    (libswiftllm_hip_<tag>.so, objects under build/<tag>/): tools/ select one with SWIFTLLM_HIP_LIB to A/B a
-    kernel parameter on the GPU box without touching the product library."""
+    """Build the library. `tag` + `defines` (-D macros) / `swap` build an EXPERIMENT variant next to it
+    (libswiftllm_hip_<tag>.so; its objects go to the system temp directory, not into the tree that ships to the GPU
+    box): tools/ select one with SWIFTLLM_HIP_LIB to A/B a kernel on the GPU box without touching the product library."""
     hipcc = _hipcc()
-    global OBJ_DIR, LIB
-    obj_dir = os.path.join(HERE, "build", tag) if tag else OBJ_DIR
+    obj_dir = os.path.join(tempfile.gettempdir(), "swiftllm_hip_variants", tag) if tag else OBJ_DIR
     lib = os.path.join(HERE, f"libswiftllm_hip_{tag}.so") if tag else LIB
     return _build(hipcc, obj_dir, lib, [f"-D{d}" for d in defines], force, jobs, verbose, swap or {})
 
@@ -105,7 +104,7 @@ if __name__ == "__main__":
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=0)
     ap.add_argument("--tag", default="", help="build an experiment variant libswiftllm_hip_<tag>.so")
-    ap.add_argument("-D", dest="defines", action="append", default=[], help="macro for the variant, e.g. SWL_PA_DEPTH=4")
+    ap.add_argument("-D", dest="defines", action="append", default=[], help="macro for the variant")
     ap.add_argument("--swap", action="append", default=[], metavar="NAME=PATH", help="compile PATH in place of source NAME")
     a = ap.parse_args()
     print(build(force=a.force, jobs=a.jobs, tag=a.tag, defines=a.defines, swap=dict(x.split("=", 1) for x in a.swap)))

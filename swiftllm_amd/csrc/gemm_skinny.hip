@@ -6,7 +6,6 @@
 //        PACKED = false      ... row-major W through a wave-private LDS transpose
 //        PACKED = true       ... W pre-packed in MFMA-fragment order (swl_gemm_pack_weight): global -> VGPR -> MFMA;
 //                                the default decode path (EngineConfig.pack_decode_weights)
-//        XNORM / EPI hooks   ... experimental fused decode layer (off by default)
 //   gemm_packed_mt_kernel    packed W, 2 or 4 blocks of 32 tokens per weight fragment (32 < M <= 128)
 //   splitk_reduce_kernel, pack_weight_kernel
 //
@@ -57,191 +56,23 @@ enum GemmMode {
     kGemmSiluGate = 2, // W = [up ; gate] (2*I rows): out[M, I] = up * silu(gate), the FFN's SiLU-gate fused in
 };
 
-// ---- decode-layer fusion hooks ---------------------------------------------------------------------
-// A decode layer is a chain of latency-bound hand-offs: GEMM -> (reduce + residual add + RMSNorm) ->
-// GEMM ..., each kernel boundary costing 5-8 us of idle HBM (measured: skipping the three small
-// kernels of a layer removes 0.72 ms of a 4.7 ms step). The hooks fold them into the GEMMs:
-//   * split-K completion: the workgroups that share an output tile count themselves in (one atomic
-//     per workgroup); the LAST one to arrive sums the slabs of that tile in slab order — so the result
-//     does not depend on who is last — and applies the consumer: residual add + per-tile sum of
-//     squares (kEpiAddResidual), or rotary + KV-cache store (kEpiRopeStore);
-//   * normalising prologue (XNORM): the x operand is the un-normalised residual stream; the per-row
-//     1/rms comes from the per-tile sums of squares the producer's epilogue left, and the norm is
-//     applied while the x tile is staged (same formula and rounding as rmsnorm.hip).
-enum GemmEpi { kEpiNone = 0, kEpiAddResidual = 1, kEpiRopeStore = 2 };
-
-struct GemmFuse {
-    // uneven K-splits (packed ring kernel, partial slabs): > 0 = the number of 128-column K-tiles of the whole
-    // projection; split y of gridDim.y takes tiles [y * total / gridDim.y, (y + 1) * total / gridDim.y) — for K that has
-    // no power-of-two split of whole tiles (Llama-2-7B's down projection: K = 11008 = 86 tiles)
+// Optional per-launch extras of the packed ring kernel.
+struct GemmExtra {
+    // uneven K-splits (partial slabs): > 0 = the number of 128-column K-tiles of the whole projection; split y of
+    // gridDim.y takes tiles [y * total / gridDim.y, (y + 1) * total / gridDim.y) — for K that has no power-of-two split
+    // of whole tiles (Llama-2-7B's down projection: K = 11008 = 86 tiles)
     int k_tiles_total;
-    // XNORM
-    const float *ssq_in; // [ssq_parts][32] partial sums of squares of the rows of x
-    const void *norm_w;  // [K]
+    // deferred RMSNorm (SiLU-gate mode): ssq_in[ssq_parts][M] partial sums of squares of the token rows behind x
+    const float *ssq_in;
     float eps;
     int ssq_parts;
-    // split-K completion
-    unsigned long long *counters; // [grid.x], zero before the launch and again after it
-    // kEpiAddResidual: residual[M][N] += round(sum slabs); ssq_out[grid.x][32]
-    void *residual;
-    float *ssq_out;
-    // kEpiRopeStore (arguments of rotary_store_decode_kernel)
-    void *q_out;
-    const void *cos_t, *sin_t;
-    const int *pos_idx;
-    void *k_cache, *v_cache;
-    const int *block_table, *seq_ids, *seq_lens;
-    int H, KVH, D, cur_layer, num_layers, block_size, max_blocks_per_seq;
-    int64_t q_tok_stride;
 };
-
-// Which of the chip's XCDs (each with its own L2) this wave runs on: HW_REG_XCC_ID, bits [3:0].
-__device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7; }
-
-// Split-K completion. Every workgroup that shares blockIdx.x adds 1 to the low byte of the tile's 64-bit
-// counter and 1 to the 6-bit field of its XCD (bits 8 + 6*xcc): one device-scope atomic per workgroup.
-// Returns 0 in all but the last arriver; there 1 if ALL the workgroups ran on this XCD — their slabs went
-// through this very L2 and plain loads see them — else 2: the slabs must be read with device-coherent loads
-// (memory has them: the stores were written through). The hardware deals consecutive workgroups round-robin
-// to the XCDs, so with gridDim.x % 8 == 0 the fast case is the rule; nothing breaks if it is not.
-__device__ __forceinline__ int splitk_arrive(unsigned long long *counters, int *flag_lds) {
-    typedef unsigned long long u64;
-    // the barrier waits for every wave's slab stores (vmcnt(0)); they are write-through stores, so once they are
-    // acknowledged the count below may be seen by a reader on any XCD
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int state = 1;
-        if (gridDim.y > 1) {
-            const int xcc = xcc_id();
-            const u64 mine = 1ull << (8 + 6 * xcc);
-            const u64 old = __hip_atomic_fetch_add(&counters[blockIdx.x], 1ull + mine, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
-            const int ks = gridDim.y;
-            if (static_cast<int>(old & 0xff) != ks - 1) {
-                state = 0;
-            } else {
-                // everybody has counted: leave it clean for the next launch
-                __hip_atomic_store(&counters[blockIdx.x], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                state = static_cast<int>(((old + mine) >> (8 + 6 * xcc)) & 63) == ks ? 1 : 2;
-            }
-        }
-        *flag_lds = state;
-    }
-    __syncthreads();
-    return *flag_lds;
-}
-
-template <typename T, bool COHERENT>
-__device__ __forceinline__ vec8_t<T> load8_slabs(const float *slabs, int ks, int64_t slab_stride, int64_t off) {
-    if constexpr (COHERENT) return load8_splitk_coherent<T>(slabs, ks, slab_stride, off);
-    else return load8_splitk<T>(slabs, ks, slab_stride, off);
-}
-
-// thread -> (row = tid / 8, 16 consecutive columns of the workgroup's 128-column tile)
-template <typename T, bool COHERENT>
-__device__ __forceinline__ void epi_add_residual(const GemmFuse &f, const float *slabs, int M, int N,
-                                                 const vec8_t<T> (&res_in)[2]) {
-    const int row = threadIdx.x >> 3, sub = threadIdx.x & 7;
-    const int ks = gridDim.y;
-    float ssq = 0.f;
-    if (row < M) {
-        const int64_t off = static_cast<int64_t>(row) * N + blockIdx.x * 128 + sub * 16;
-        T *res = static_cast<T *>(f.residual) + off;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            vec8_t<T> xv = load8_slabs<T, COHERENT>(slabs, ks, static_cast<int64_t>(M) * N, off + c * 8);
-            const vec8_t<T> rv = res_in[c];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xv[j] = add_t<T>(xv[j], rv[j]); // rounded to T, as stored
-            store8(res + c * 8, xv);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float v = to_f(xv[j]);
-                ssq = fmaf(v, v, ssq);
-            }
-        }
-    }
-    ssq += __shfl_xor(ssq, 1, 64);
-    ssq += __shfl_xor(ssq, 2, 64);
-    ssq += __shfl_xor(ssq, 4, 64);
-    if (sub == 0 && row < M) f.ssq_out[blockIdx.x * 32 + row] = ssq;
-}
-
-// One item of 16 columns per thread: a (head, chunk) rotation pair of a q/k head, or 16 consecutive
-// columns of a v head. Same loads, arithmetic and stores as rotary_store_decode_kernel (rotary.hip).
-template <typename T, bool COHERENT>
-__device__ __forceinline__ void epi_rope_store(const GemmFuse &f, const float *slabs, int M, int N) {
-    const int row = threadIdx.x >> 3, sub = threadIdx.x & 7;
-    if (row >= M) return;
-    const int ks = gridDim.y;
-    const int D = f.D;
-    const int per_head = D >> 4; // items per head
-    const int hc = blockIdx.x * 128 + (sub / per_head) * D; // first column of this item's head
-    const int c = sub % per_head;
-    const int q_cols = f.H * D, k_cols = f.KVH * D;
-    const int64_t slab_stride = static_cast<int64_t>(M) * N;
-    const int64_t row_off = static_cast<int64_t>(row) * N;
-    const int pos = f.seq_lens[row] - 1;
-    int64_t pool = 0; // offset of (block, layer, kv head, slot, 0) in the pools
-    if (hc >= q_cols) {
-        const int kvh = (hc - q_cols) / D % f.KVH;
-        const int64_t blk = f.block_table[static_cast<int64_t>(f.seq_ids[row]) * f.max_blocks_per_seq +
-                                          pos / f.block_size];
-        pool = (((blk * f.num_layers + f.cur_layer) * f.KVH + kvh) * static_cast<int64_t>(f.block_size) +
-                pos % f.block_size) * D;
-    }
-    if (hc < q_cols + k_cols) {
-        const int64_t trow = f.pos_idx ? f.pos_idx[row] : pos;
-        const vec8_t<T> cv = load8(static_cast<const T *>(f.cos_t) + trow * (D >> 1) + c * 8);
-        const vec8_t<T> sv = load8(static_cast<const T *>(f.sin_t) + trow * (D >> 1) + c * 8);
-        vec8_t<T> x0 = load8_slabs<T, COHERENT>(slabs, ks, slab_stride, row_off + hc + c * 8);
-        vec8_t<T> x1 = load8_slabs<T, COHERENT>(slabs, ks, slab_stride, row_off + hc + (D >> 1) + c * 8);
-        rotate8<T>(x0, x1, cv, sv);
-        T *dst = hc < q_cols ? static_cast<T *>(f.q_out) + row * f.q_tok_stride + hc
-                             : static_cast<T *>(f.k_cache) + pool;
-        store8(dst + c * 8, x0);
-        store8(dst + (D >> 1) + c * 8, x1);
-    } else {
-        T *dst = static_cast<T *>(f.v_cache) + pool + c * 16;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            store8(dst + h * 8, load8_slabs<T, COHERENT>(slabs, ks, slab_stride, row_off + hc + c * 16 + h * 8));
-    }
-}
-
-template <typename T, int EPI>
-__device__ __forceinline__ void splitk_finish(const GemmFuse &f, const float *slabs, int *flag_lds, int M,
-                                              int N) {
-    if constexpr (EPI != kEpiNone) {
-        // the residual tile does not depend on the slabs: every workgroup fetches it before the count (8 KiB,
-        // wasted in all but the last arriver) so its HBM latency is off the last arriver's critical path
-        vec8_t<T> res_in[2] = {};
-        if constexpr (EPI == kEpiAddResidual) {
-            const int row = threadIdx.x >> 3, sub = threadIdx.x & 7;
-            if (row < M) {
-                const T *res = static_cast<const T *>(f.residual) + static_cast<int64_t>(row) * N +
-                               blockIdx.x * 128 + sub * 16;
-                res_in[0] = load8(res);
-                res_in[1] = load8(res + 8);
-            }
-        }
-        const int state = splitk_arrive(f.counters, flag_lds);
-        if (state == 0) return;
-        if (state == 1) {
-            if constexpr (EPI == kEpiAddResidual) epi_add_residual<T, false>(f, slabs, M, N, res_in);
-            else epi_rope_store<T, false>(f, slabs, M, N);
-        } else {
-            if constexpr (EPI == kEpiAddResidual) epi_add_residual<T, true>(f, slabs, M, N, res_in);
-            else epi_rope_store<T, true>(f, slabs, M, N);
-        }
-    }
-}
 
 // acc[r] = out^T[n = n0 + (r&3) + 8*(r>>2) + 4*hf][m = l32] -> the three output modes.
 // `wtiles + w * wave_pitch` is wave w's private W tile (reused as exchange space in SiLU-gate mode).
 // `rs`: deferred-RMSNorm row scale of token m = lane % 32 (rmsnorm.hip: splitk_add_scale_kernel), applied in fp32
 // before the projection's one rounding; 1.0f (exact no-op) everywhere else.
-template <typename T, int MODE, bool COHERENT = false>
+template <typename T, int MODE>
 __device__ __forceinline__ void gemm_epilogue(const float16_t &acc, void *__restrict__ out_, T *wtiles,
                                               int wave_pitch, int wave, int lane, bool is_gate, bool tile_ok,
                                               int col0, int n0, int ksplit, int M, int N, int64_t out_stride,
@@ -282,8 +113,7 @@ __device__ __forceinline__ void gemm_epilogue(const float16_t &acc, void *__rest
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const float4_t v = {acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]};
-                if constexpr (COHERENT) store_f4_coherent(slab + 8 * r4, v); // read back within this kernel
-                else *reinterpret_cast<float4_t *>(slab + 8 * r4) = v;
+                *reinterpret_cast<float4_t *>(slab + 8 * r4) = v;
             }
         } else {
             typedef T vec4 __attribute__((ext_vector_type(4)));
@@ -299,11 +129,11 @@ __device__ __forceinline__ void gemm_epilogue(const float16_t &acc, void *__rest
     }
 }
 
-template <typename T, int MODE, int EPI = kEpiNone>
+template <typename T, int MODE>
 // 2 waves per SIMD (<= 256 registers): two 4-wave workgroups per CU = 64 KiB of W in flight per CU
 __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_skinny_kernel(
     void *__restrict__ out_, const T *__restrict__ x, const T *__restrict__ w, int M, int N, int K,
-    int kc, int64_t x_stride, int64_t out_stride, GemmFuse fuse) {
+    int kc, int64_t x_stride, int64_t out_stride) {
     // [wave][0 = W tile, 1 = x tile][32 rows x 128 elements, 16-byte slots XOR-swizzled per row]
     __shared__ __attribute__((aligned(16))) T lds[kGemmWaves][2][32 * kKT];
 
@@ -382,15 +212,12 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_skinny_kernel(
     }
 
     mfma_results_ready<8>(acc); // acc comes straight out of the K loop (swl_common.h)
-    gemm_epilogue<T, MODE, EPI != kEpiNone>(acc, out_, &lds[0][0][0], 2 * 32 * kKT, wave, lane, is_gate, tile_ok, col0, n0,
-                           ksplit, M, N, out_stride);
-    // (fused launches have N % 128 == 0: no wave left above, every thread reaches the barriers)
-    splitk_finish<T, EPI>(fuse, static_cast<const float *>(out_), reinterpret_cast<int *>(&lds[0][0][0]), M, N);
+    gemm_epilogue<T, MODE>(acc, out_, &lds[0][0][0], 2 * 32 * kKT, wave, lane, is_gate, tile_ok, col0, n0, ksplit, M, N,
+                           out_stride);
 }
 
 // ---- RING variant: x tile shared by the workgroup, kRing-deep register ring of W tiles --------------
 constexpr int kRing = 3;
-constexpr int kMaxNormK = 4096; // XNORM: K-chunk whose norm weight fits the 8 KiB LDS slice
 
 // PACKED: W comes pre-packed in MFMA-fragment order (swl_gemm_pack_weight: [N/32][K/16][64 lanes][8]) — the A
 // operand of one v_mfma_f32_32x32x16 is ONE contiguous KiB and a wave's whole K range for its 32 rows one
@@ -402,21 +229,17 @@ constexpr int kMaxNormK = 4096; // XNORM: K-chunk whose norm weight fits the 8 K
 // three — the fused qkv projection of Llama-3-8B is 192 tiles x 4 K-splits = 768 wave-chunks: 192 four-wave workgroups
 // leave a quarter of the 256 CUs idle, 256 three-wave ones fill the chip (r02). Three waves stage the 8 row-groups of the
 // x tile as 3 + 3 + 2: the ninth (dummy) group is a clamped load into four spare LDS rows — no branch in the pipeline.
-template <typename T, int MODE, bool XNORM = false, int EPI = kEpiNone, bool PACKED = false, int RD = kRing,
-          int NWV = kGemmWaves>
+template <typename T, int MODE, bool PACKED = false, int RD = kRing, int NWV = kGemmWaves>
 // 2 waves per SIMD: the ring holds RD x 8 KiB of W per wave in registers (~220 VGPRs at RD = 3)
 __global__ __launch_bounds__(NWV * 64, 2) void gemm_skinny_ring_kernel(
     void *__restrict__ out_, const T *__restrict__ x, const T *__restrict__ w, int M, int N, int K,
-    int kc, int64_t x_stride, int64_t out_stride, GemmFuse fuse) {
-    static_assert(!PACKED || (!XNORM && EPI == kEpiNone), "the fusion hooks are built on the row-major kernels");
+    int kc, int64_t x_stride, int64_t out_stride, GemmExtra fuse) {
     static_assert(NWV == kGemmWaves || (NWV == 3 && PACKED && MODE == kGemmPartial), "3 waves: packed partial only");
     constexpr int D = RD;
     constexpr int XL = (8 + NWV - 1) / NWV; // x row-groups (4 rows each) a wave stages per tile
     constexpr int XROWS = 4 * XL * NWV;      // 32, or 36 with the dummy group of the 3-wave variant
     // [0..1] the double-buffered x tile of the workgroup, [2 + wave] the wave-private W tile (row-major W only)
     __shared__ __attribute__((aligned(16))) T lds[2 + (PACKED ? 0 : kGemmWaves)][XROWS * kKT];
-    __shared__ __attribute__((aligned(16))) T gl[XNORM ? kMaxNormK : 8]; // norm weight of the K-chunk
-    __shared__ float rs[32];                                              // XNORM: 1/rms per row
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -458,12 +281,10 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_skinny_ring_kernel(
     const int hf = lane >> 5;
     T *wl = &lds[PACKED ? 0 : 2 + wave][0]; // (unused when PACKED)
 
-    float rstd[XL];
-
     // deferred RMSNorm (SiLU-gate mode, packed W): the per-1024-column sums of squares of this lane's token row, requested
     // BEFORE the weight stream (oldest loads: no wait of the pipeline ever includes them) and summed after the K loop
     float ssv[8];
-    const bool row_scaled = !XNORM && EPI == kEpiNone && fuse.ssq_in != nullptr;
+    const bool row_scaled = PACKED && MODE == kGemmSiluGate && fuse.ssq_in != nullptr;
     if (row_scaled) {
         const int m = min(lane & 31, M - 1);
 #pragma unroll
@@ -483,13 +304,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_skinny_ring_kernel(
 #define SWL_STAGE_X(slot, buf, tile)                                                                 \
     {                                                                                                \
         _Pragma("unroll") for (int q_ = 0; q_ < XL; ++q_) {                                          \
-            vec8_t<T> xv_ = xr[slot][q_];                                                            \
-            if constexpr (XNORM) { /* rmsnorm.hip: round(float(x) * rstd * float(w)) */              \
-                const vec8_t<T> gv_ = *reinterpret_cast<const vec8_t<T> *>(&gl[(tile) * kKT + chunk * 8]); \
-                _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_)                                     \
-                    xv_[j_] = to_t<T>(to_f(xv_[j_]) * rstd[q_] * to_f(gv_[j_]));                     \
-            }                                                                                        \
-            *reinterpret_cast<vec8_t<T> *>(&lds[buf][xs_wr[q_]]) = xv_;                              \
+            *reinterpret_cast<vec8_t<T> *>(&lds[buf][xs_wr[q_]]) = xr[slot][q_];                     \
         }                                                                                            \
     }
 #define SWL_PROCESS(slot, buf)                                                                       \
@@ -514,35 +329,6 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_skinny_ring_kernel(
 #pragma unroll
     for (int d = 0; d < D - 1; ++d)
         if (d < nkt) SWL_ISSUE(d, d);
-    if constexpr (XNORM) {
-        // (after the W loads are on their way) 1/rms of the rows this lane stages, from the producer's per-tile
-        // sums of squares, added in tile order; the norm weight of this K-chunk goes to LDS for the whole
-        // kernel (kc <= kMaxNormK: host check)
-        const T *g = static_cast<const T *>(fuse.norm_w) + k_begin;
-        for (int i = threadIdx.x * 8; i < kc; i += kGemmWaves * 64 * 8)
-            *reinterpret_cast<vec8_t<T> *>(&gl[i]) = load8(g + i);
-        {   // one memory round trip: thread -> (row = tid / 8, parts sub, sub + 8, ...), 8-lane butterfly
-            const int row = threadIdx.x >> 3, sub = threadIdx.x & 7;
-            float part_sum = 0.f;
-            if (row < M) {
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
-                int part = sub;
-                for (; part + 24 < fuse.ssq_parts; part += 32) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] += fuse.ssq_in[(part + 8 * u) * 32 + row];
-                }
-                for (; part < fuse.ssq_parts; part += 8) v[0] += fuse.ssq_in[part * 32 + row];
-                part_sum = (v[0] + v[1]) + (v[2] + v[3]);
-            }
-            part_sum += __shfl_xor(part_sum, 1, 64);
-            part_sum += __shfl_xor(part_sum, 2, 64);
-            part_sum += __shfl_xor(part_sum, 4, 64);
-            if (sub == 0) rs[row] = 1.0f / sqrtf(part_sum / static_cast<float>(K) + fuse.eps);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < XL; ++q) rstd[q] = rs[min(4 * (wave * XL + q) + rsub, M - 1)];
-    }
     SWL_STAGE_X(0, 0, 0);
     __syncthreads();
     int kt = 0;
@@ -584,12 +370,11 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_skinny_ring_kernel(
             const float ss = ((ssv[0] + ssv[1]) + (ssv[2] + ssv[3])) + ((ssv[4] + ssv[5]) + (ssv[6] + ssv[7]));
             rs = 1.0f / sqrtf(ss / static_cast<float>(K) + fuse.eps); // rmsnorm.hip's formula
         }
-        gemm_epilogue<T, MODE, false>(acc, out_, &lds[0][0], 32 * 40, wave, lane, is_gate, tile_ok, col0, n0, ksplit,
-                                      M, N, out_stride, rs);
+        gemm_epilogue<T, MODE>(acc, out_, &lds[0][0], 32 * 40, wave, lane, is_gate, tile_ok, col0, n0, ksplit, M, N,
+                               out_stride, rs);
     } else {
-        gemm_epilogue<T, MODE, EPI != kEpiNone>(acc, out_, &lds[PACKED ? 0 : 2][0], 32 * kKT, wave, lane, is_gate,
-                                                tile_ok, col0, n0, ksplit, M, N, out_stride);
-        splitk_finish<T, EPI>(fuse, static_cast<const float *>(out_), reinterpret_cast<int *>(&lds[0][0]), M, N);
+        gemm_epilogue<T, MODE>(acc, out_, &lds[PACKED ? 0 : 2][0], 32 * kKT, wave, lane, is_gate, tile_ok, col0, n0,
+                               ksplit, M, N, out_stride);
     }
 }
 
@@ -661,19 +446,19 @@ static int run_gemm(T *out, const T *x, const T *w, float *ws, size_t ws_bytes, 
     if (ks == 1 && reduce) {
         if (ring)
             hipLaunchKernelGGL((gemm_skinny_ring_kernel<T, kGemmDirect>), grid, dim3(kGemmWaves * 64), 0, stream,
-                               out, x, w, M, N, K, kc, xs, os, GemmFuse{});
+                               out, x, w, M, N, K, kc, xs, os, GemmExtra{});
         else
             hipLaunchKernelGGL((gemm_skinny_kernel<T, kGemmDirect>), grid, dim3(kGemmWaves * 64), 0, stream, out,
-                               x, w, M, N, K, kc, xs, os, GemmFuse{});
+                               x, w, M, N, K, kc, xs, os);
         return check_launch();
     }
     if (!ws || ws_bytes < static_cast<size_t>(ks) * M * N * sizeof(float)) return SWL_ERR_BAD_ARG;
     if (ring)
         hipLaunchKernelGGL((gemm_skinny_ring_kernel<T, kGemmPartial>), grid, dim3(kGemmWaves * 64), 0, stream, ws,
-                           x, w, M, N, K, kc, xs, static_cast<int64_t>(N), GemmFuse{});
+                           x, w, M, N, K, kc, xs, static_cast<int64_t>(N), GemmExtra{});
     else
         hipLaunchKernelGGL((gemm_skinny_kernel<T, kGemmPartial>), grid, dim3(kGemmWaves * 64), 0, stream, ws, x, w,
-                           M, N, K, kc, xs, static_cast<int64_t>(N), GemmFuse{});
+                           M, N, K, kc, xs, static_cast<int64_t>(N));
     if (!reduce) return check_launch();
     const int64_t items = static_cast<int64_t>(M) * (N / 4);
     const unsigned rgrid = static_cast<unsigned>((items + 255) / 256);
@@ -782,164 +567,14 @@ extern "C" int swl_gemm_skinny_silu_gate(void *out, const void *x, const void *w
             hipLaunchKernelGGL((swl::gemm_skinny_ring_kernel<T, swl::kGemmSiluGate>), grid,
                                dim3(swl::kGemmWaves * 64), 0, static_cast<hipStream_t>(stream), out,
                                static_cast<const T *>(x), static_cast<const T *>(w_up_gate), M, I, K, K,
-                               x_row_stride, out_row_stride, swl::GemmFuse{});
+                               x_row_stride, out_row_stride, swl::GemmExtra{});
         else
             hipLaunchKernelGGL((swl::gemm_skinny_kernel<T, swl::kGemmSiluGate>), grid,
                                dim3(swl::kGemmWaves * 64), 0, static_cast<hipStream_t>(stream), out,
                                static_cast<const T *>(x), static_cast<const T *>(w_up_gate), M, I, K, K,
-                               x_row_stride, out_row_stride, swl::GemmFuse{});
+                               x_row_stride, out_row_stride);
     });
     return swl::check_launch();
-}
-
-// ---- fused decode-layer projections (see "decode-layer fusion hooks" above) ---------------------------
-namespace swl {
-
-static bool fused_shape_ok(int M, int N, int K) {
-    return M > 0 && M <= 32 && N > 0 && (N & 127) == 0 && K > 0 && (K & (kKT - 1)) == 0;
-}
-
-// One split-K launch whose last-arriving workgroup per tile runs the EPI consumer. XNORM forces the ring kernel.
-template <typename T, int EPI>
-static int run_fused_partial(const T *x, const T *w, float *slabs, size_t slabs_bytes, int counters_len, int M,
-                             int N, int K, int64_t xs, const GemmFuse &f_in, bool xnorm, hipStream_t stream) {
-    const int ks = choose_k_splits(N, K);
-    if (slabs_bytes < static_cast<size_t>(ks) * M * N * sizeof(float) || counters_len < N / 128)
-        return SWL_ERR_BAD_ARG;
-    const GemmFuse &f = f_in;
-    const int kc = K / ks;
-    const dim3 grid(N / 128, ks), block(kGemmWaves * 64);
-    const int64_t os = N;
-    if (xnorm && kc > kMaxNormK) return SWL_ERR_UNSUPPORTED;
-    if (xnorm)
-        hipLaunchKernelGGL((gemm_skinny_ring_kernel<T, kGemmPartial, true, EPI>), grid, block, 0, stream, slabs, x,
-                           w, M, N, K, kc, xs, os, f);
-    else if (use_ring(kc))
-        hipLaunchKernelGGL((gemm_skinny_ring_kernel<T, kGemmPartial, false, EPI>), grid, block, 0, stream, slabs,
-                           x, w, M, N, K, kc, xs, os, f);
-    else
-        hipLaunchKernelGGL((gemm_skinny_kernel<T, kGemmPartial, EPI>), grid, block, 0, stream, slabs, x, w, M, N,
-                           K, kc, xs, os, f);
-    return check_launch();
-}
-
-} // namespace swl
-
-/* residual[M, N] += round(x . W^T)  and  ssq_out[N/128][32] = per-128-column-tile sums of squares of the
- * updated residual rows — the residual-add half of fused_add_rmsnorm (reference rmsnorm.py:39-65) folded into
- * the o_proj / down_proj GEMM; the normalising half is applied by the consumer GEMM (swl_gemm_skinny_norm_*). */
-extern "C" int swl_gemm_skinny_add_residual(void *residual, float *ssq_out, const void *x, const void *w,
-                                            float *slabs, size_t slabs_bytes, int64_t *counters,
-                                            int32_t counters_len, int32_t M, int32_t N, int32_t K,
-                                            int64_t x_row_stride, int32_t dtype, swl_stream_t stream) {
-    if (M == 0) return SWL_OK;
-    if (!swl::fused_shape_ok(M, N, K)) return SWL_ERR_UNSUPPORTED;
-    if (!residual || !ssq_out || !x || !w || !slabs || !counters) return SWL_ERR_BAD_ARG;
-    if (x_row_stride < K || (x_row_stride & 7) || !swl::aligned16(x) || !swl::aligned16(w) ||
-        !swl::aligned16(slabs) || !swl::aligned16(residual))
-        return SWL_ERR_BAD_ARG;
-    swl::GemmFuse f{};
-    f.counters = reinterpret_cast<unsigned long long *>(counters);
-    f.residual = residual;
-    f.ssq_out = ssq_out;
-    SWL_DISPATCH_DTYPE(dtype, T, {
-        return swl::run_fused_partial<T, swl::kEpiAddResidual>(
-            static_cast<const T *>(x), static_cast<const T *>(w), slabs, slabs_bytes, counters_len, M, N, K,
-            x_row_stride, f, false, static_cast<hipStream_t>(stream));
-    });
-}
-
-/* out[M, I] = up * silu(gate) of rmsnorm(x) . [up ; gate]^T where x is the un-normalised residual stream and
- * ssq_in[ssq_parts][32] its per-tile row sums of squares (from swl_gemm_skinny_add_residual): the normalising
- * half of fused_add_rmsnorm + linear + silu_and_mul in one launch (transformer_layer.py:121-127). */
-extern "C" int swl_gemm_skinny_norm_silu_gate(void *out, const void *x, const float *ssq_in, int32_t ssq_parts,
-                                              const void *norm_w, float eps, const void *w_up_gate, int32_t M,
-                                              int32_t I, int32_t K, int64_t x_row_stride,
-                                              int64_t out_row_stride, int32_t dtype, swl_stream_t stream) {
-    if (M < 0 || I <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
-    if (M == 0) return SWL_OK;
-    if (!out || !x || !w_up_gate || !ssq_in || !norm_w || ssq_parts <= 0) return SWL_ERR_BAD_ARG;
-    if (M > 32 || (I & 31) || (K & (swl::kKT - 1)) || K > swl::kMaxNormK) return SWL_ERR_UNSUPPORTED;
-    if (x_row_stride < K || out_row_stride < I || (x_row_stride & 7) || (out_row_stride & 3))
-        return SWL_ERR_BAD_ARG;
-    if (!swl::aligned16(x) || !swl::aligned16(w_up_gate) || !swl::aligned16(norm_w) ||
-        (reinterpret_cast<uintptr_t>(out) & 7u))
-        return SWL_ERR_BAD_ARG;
-    swl::GemmFuse f{};
-    f.ssq_in = ssq_in;
-    f.ssq_parts = ssq_parts;
-    f.norm_w = norm_w;
-    f.eps = eps;
-    const dim3 grid((I / 32 + 1) / 2, 1);
-    SWL_DISPATCH_DTYPE(dtype, T, {
-        hipLaunchKernelGGL((swl::gemm_skinny_ring_kernel<T, swl::kGemmSiluGate, true, swl::kEpiNone>), grid,
-                           dim3(swl::kGemmWaves * 64), 0, static_cast<hipStream_t>(stream), out,
-                           static_cast<const T *>(x), static_cast<const T *>(w_up_gate), M, I, K, K, x_row_stride,
-                           out_row_stride, f);
-    });
-    return swl::check_launch();
-}
-
-/* Fused qkv projection of a decode batch with rotary embedding and the KV-cache store in its epilogue
- * (transformer_layer.py:54-56 + rotary_emb.py + kvcache_mgmt.py:50-79): q_out[M, H, D] gets the rotated
- * queries, the rotated keys and the values go straight to their (block, slot) in the pools. With ssq_in the x
- * operand is the un-normalised residual stream and the attention RMSNorm is applied on the fly; with
- * ssq_in == NULL x is used as it is. (H + 2*KVH) * D % 128 == 0, D in {32, 64, 128}, M <= 32. */
-extern "C" int swl_gemm_skinny_qkv_rope_store(
-    void *q_out, const void *x, const float *ssq_in, int32_t ssq_parts, const void *norm_w, float eps,
-    const void *w_qkv, float *slabs, size_t slabs_bytes, int64_t *counters, int32_t counters_len,
-    const void *cos_table, const void *sin_table, const int32_t *pos_idx, void *k_cache, void *v_cache,
-    const int32_t *block_table, const int32_t *seq_ids, const int32_t *seq_lens, int32_t num_decoding_seqs,
-    int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, int32_t K, int32_t cur_layer,
-    int32_t num_layers, int32_t block_size, int32_t max_blocks_per_seq, int64_t q_tok_stride,
-    int64_t x_row_stride, int32_t dtype, swl_stream_t stream) {
-    const int M = num_decoding_seqs;
-    if (M == 0) return SWL_OK;
-    if (num_q_heads <= 0 || num_kv_heads <= 0 || !(head_dim == 32 || head_dim == 64 || head_dim == 128))
-        return SWL_ERR_UNSUPPORTED;
-    const int N = (num_q_heads + 2 * num_kv_heads) * head_dim;
-    if (!swl::fused_shape_ok(M, N, K)) return SWL_ERR_UNSUPPORTED;
-    if (!q_out || !x || !w_qkv || !slabs || !counters || !cos_table || !sin_table || !k_cache || !v_cache ||
-        !block_table || !seq_ids || !seq_lens)
-        return SWL_ERR_BAD_ARG;
-    if (ssq_in && (!norm_w || ssq_parts <= 0 || !swl::aligned16(norm_w))) return SWL_ERR_BAD_ARG;
-    if (x_row_stride < K || (x_row_stride & 7) || q_tok_stride < static_cast<int64_t>(num_q_heads) * head_dim ||
-        (q_tok_stride & 7))
-        return SWL_ERR_BAD_ARG;
-    if (!swl::aligned16(x) || !swl::aligned16(w_qkv) || !swl::aligned16(slabs) || !swl::aligned16(q_out) ||
-        !swl::aligned16(k_cache) || !swl::aligned16(v_cache) || !swl::aligned16(cos_table) ||
-        !swl::aligned16(sin_table))
-        return SWL_ERR_BAD_ARG;
-    if (block_size <= 0 || num_layers <= 0 || cur_layer < 0 || cur_layer >= num_layers || max_blocks_per_seq <= 0)
-        return SWL_ERR_BAD_ARG;
-    swl::GemmFuse f{};
-    f.ssq_in = ssq_in;
-    f.ssq_parts = ssq_parts;
-    f.norm_w = norm_w;
-    f.eps = eps;
-    f.counters = reinterpret_cast<unsigned long long *>(counters);
-    f.q_out = q_out;
-    f.cos_t = cos_table;
-    f.sin_t = sin_table;
-    f.pos_idx = pos_idx;
-    f.k_cache = k_cache;
-    f.v_cache = v_cache;
-    f.block_table = block_table;
-    f.seq_ids = seq_ids;
-    f.seq_lens = seq_lens;
-    f.H = num_q_heads;
-    f.KVH = num_kv_heads;
-    f.D = head_dim;
-    f.cur_layer = cur_layer;
-    f.num_layers = num_layers;
-    f.block_size = block_size;
-    f.max_blocks_per_seq = max_blocks_per_seq;
-    f.q_tok_stride = q_tok_stride;
-    SWL_DISPATCH_DTYPE(dtype, T, {
-        return swl::run_fused_partial<T, swl::kEpiRopeStore>(
-            static_cast<const T *>(x), static_cast<const T *>(w_qkv), slabs, slabs_bytes, counters_len, M, N, K,
-            x_row_stride, f, ssq_in != nullptr, static_cast<hipStream_t>(stream));
-    });
 }
 
 // ---- pre-packed weights (PACKED ring kernel) ------------------------------------------------------------------
@@ -972,21 +607,21 @@ static void launch_packed_partial3(hipStream_t stream, void *out, const T *x, co
                                    int ks, int64_t xs) {
     const dim3 grid(N / 32 / 3, ks);
     if (use_ring(kc))
-        hipLaunchKernelGGL((gemm_skinny_ring_kernel<T, kGemmPartial, false, kEpiNone, true, 3, 3>), grid, dim3(3 * 64), 0,
-                           stream, out, x, wp, M, N, K, kc, xs, static_cast<int64_t>(N), GemmFuse{});
+        hipLaunchKernelGGL((gemm_skinny_ring_kernel<T, kGemmPartial, true, 3, 3>), grid, dim3(3 * 64), 0,
+                           stream, out, x, wp, M, N, K, kc, xs, static_cast<int64_t>(N), GemmExtra{});
     else
-        hipLaunchKernelGGL((gemm_skinny_ring_kernel<T, kGemmPartial, false, kEpiNone, true, 2, 3>), grid, dim3(3 * 64), 0,
-                           stream, out, x, wp, M, N, K, kc, xs, static_cast<int64_t>(N), GemmFuse{});
+        hipLaunchKernelGGL((gemm_skinny_ring_kernel<T, kGemmPartial, true, 2, 3>), grid, dim3(3 * 64), 0,
+                           stream, out, x, wp, M, N, K, kc, xs, static_cast<int64_t>(N), GemmExtra{});
 }
 
 template <typename T, int MODE>
 static void launch_packed(dim3 grid, hipStream_t stream, void *out, const T *x, const T *wp, int M, int N, int K, int kc,
-                          int64_t xs, int64_t os, const GemmFuse &fuse = GemmFuse{}) {
+                          int64_t xs, int64_t os, const GemmExtra &fuse = GemmExtra{}) {
     if (use_ring(kc))
-        hipLaunchKernelGGL((gemm_skinny_ring_kernel<T, MODE, false, kEpiNone, true, 3>), grid, dim3(kGemmWaves * 64), 0,
+        hipLaunchKernelGGL((gemm_skinny_ring_kernel<T, MODE, true, 3>), grid, dim3(kGemmWaves * 64), 0,
                            stream, out, x, wp, M, N, K, kc, xs, os, fuse);
     else
-        hipLaunchKernelGGL((gemm_skinny_ring_kernel<T, MODE, false, kEpiNone, true, 2>), grid, dim3(kGemmWaves * 64), 0,
+        hipLaunchKernelGGL((gemm_skinny_ring_kernel<T, MODE, true, 2>), grid, dim3(kGemmWaves * 64), 0,
                            stream, out, x, wp, M, N, K, kc, xs, os, fuse);
 }
 
@@ -1004,7 +639,7 @@ static int run_gemm_packed(T *out, const T *x, const T *wp, float *ws, size_t ws
         return check_launch();
     }
     if (!ws || ws_bytes < static_cast<size_t>(ks) * M * N * sizeof(float)) return SWL_ERR_BAD_ARG;
-    GemmFuse fuse{};
+    GemmExtra fuse{};
     fuse.k_tiles_total = uneven ? K / kKT : 0;
     if (!uneven && prefer_three_waves(N, ks)) launch_packed_partial3<T>(stream, ws, x, wp, M, N, K, kc, ks, xs);
     else launch_packed<T, kGemmPartial>(grid, stream, ws, x, wp, M, N, K, kc, xs, static_cast<int64_t>(N), fuse);
@@ -1108,7 +743,7 @@ extern "C" int swl_gemm_skinny_packed_silu_gate_rs(void *out, const void *x, con
     if (x_row_stride < K || out_row_stride < I || (x_row_stride & 7) || (out_row_stride & 3)) return SWL_ERR_BAD_ARG;
     if (!swl::aligned16(x) || !swl::aligned16(w_up_gate_packed) || (reinterpret_cast<uintptr_t>(out) & 7u))
         return SWL_ERR_BAD_ARG;
-    swl::GemmFuse f{};
+    swl::GemmExtra f{};
     f.ssq_in = row_ssq;
     f.ssq_parts = ssq_parts;
     f.eps = eps;

@@ -81,16 +81,6 @@ __device__ __forceinline__ void attend_block(const vec8_t<T> (&qv)[G],
                                              float c, int tok0, int row, int len, bool partial) {
     using Tile = DecodeTile<T, D, G>;
     constexpr int NI = Tile::NI;
-#ifdef SWL_PA_PROBE_NO_MATH
-    // A/B build only (tools/gpu_attn_variants.sh): the K/V stream with next to no arithmetic — how far from the
-    // memory-only time is the kernel? Results are meaningless.
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; j += 2)
-            acc[0][j] += __builtin_bit_cast(float, vec2_t<T>{Kv[i][j], Vv[i][j + 1]});
-    return;
-#endif
     float vf[NI][8];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -276,19 +266,9 @@ __device__ __forceinline__ void attend_block_mfma(const vec8_t<T> (&qb)[MfmaTile
 // Ring depth of the K/V register pipeline: a wave keeps kPaDepth 16-token blocks (K + V = 8 KiB, 32 VGPRs each)
 // resident — the one it attends plus kPaDepth-1 in flight. Little's law on this part: one CU needs ~31 GB/s
 // (8 TB/s / 256) against ~2 us of loaded HBM latency = ~64 KB in flight; 8 waves x 1 block in flight (depth 2) is
-// exactly that with nothing to spare, depth 3 doubles it.
-#ifndef SWL_PA_DEPTH
-#define SWL_PA_DEPTH 0      // 0 = by group size (below); an explicit value is for A/B builds
-#endif
-// L2 look-ahead: besides the register ring, a wave touches (one 4-byte load per 128-byte line: lanes 0-31 the K
-// tile, lanes 32-63 the V tile) the block it will load SWL_PA_L2_AHEAD ring rounds later, so the HBM round trip of
-// that block is already under way — bytes in flight per CU stop being bounded by the VGPR file. 0 = off.
-#ifndef SWL_PA_L2_AHEAD
-#define SWL_PA_L2_AHEAD 0
-#endif
-#ifndef SWL_PA_MFMA_DEPTH
-#define SWL_PA_MFMA_DEPTH 2
-#endif
+// exactly that with nothing to spare, depth 3 doubles it. (r02 A/B builds of deeper rings and of an L2 look-ahead touch
+// lost or tied — profiles/r02g_paged_attn_mfma.md; the knobs are gone, the numbers stay there.)
+constexpr int kPaMfmaDepth = 2;   // matrix-core path (G >= 2): measured best on MI355X (profiles/r02g_paged_attn_mfma.md)
 
 // NW = waves per workgroup: 4 for short sequence blocks (latency-bound launches that want many
 // small workgroups), 8 for long ones (one workgroup per CU, every wave streams many KV blocks and the
@@ -315,11 +295,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
     __shared__ float sm_acc[NW][G][D];
     __shared__ __attribute__((aligned(16))) T sm_q[QKV ? G * D : 8];
     __shared__ __attribute__((aligned(16))) T sm_kv[QKV ? 2 * D : 8];
-#ifdef SWL_PA_NO_MFMA
-    constexpr bool MF = false;           // A/B build: the VALU attend_block for every G
-#else
     constexpr bool MF = G >= 2;          // matrix-core attend_block (see attend_block_mfma)
-#endif
     using MT = MfmaTile<T, D>;
     __shared__ __attribute__((aligned(16))) T sm_stage[MF ? NW : 1][MF ? MT::ELEMS : 8];
 
@@ -371,10 +347,9 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
     float m[MF ? 1 : G], l[MF ? 1 : G], acc[MF ? 1 : G][8];
     float4_t acc4[MT::OS];              // MF: O^T[d = 16 mm + 4 q + r][head h]
 
-    // ring slots: what the 256-VGPR budget of a 2-waves-per-SIMD kernel holds without spilling (accumulators grow
-    // with G): G = 1 -> 4, G = 2 -> 3, G >= 4 -> 2
-    // (the matrix-core path keeps D/16 x 4 accumulator registers whatever G is: 3 slots for every G >= 2)
-    constexpr int ND = SWL_PA_DEPTH > 0 ? ((G >= 8 && !MF) ? 2 : SWL_PA_DEPTH) : (G == 1 ? 4 : (MF ? SWL_PA_MFMA_DEPTH : (G == 2 ? 3 : 2)));
+    // ring slots: what the 256-VGPR budget of a 2-waves-per-SIMD kernel holds without spilling: 4 for the VALU path
+    // (G = 1), kPaMfmaDepth for the matrix-core path (D/16 x 4 accumulator registers whatever G is)
+    constexpr int ND = G == 1 ? 4 : kPaMfmaDepth;
     vec8_t<T> Kr[ND][NI], Vr[ND][NI];
     auto load_phys = [&](int64_t phys, vec8_t<T>(&Kd)[NI], vec8_t<T>(&Vd)[NI]) {
         const int64_t base = (phys * blk_pitch + layer_head) * tile_elems + lane * 8;
@@ -411,19 +386,6 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
             }
         }
         attend(b, Kd, Vd);
-    };
-    // L2 look-ahead for block bb (see SWL_PA_L2_AHEAD). The load is hidden from the compiler's vmcnt bookkeeping
-    // (inline asm): its result is never read; `pf` pins one VGPR for the whole loop so nothing else is allocated
-    // where the in-flight loads land. The compiler's counted waits can only over-wait because of it.
-    int pf = 0;
-    auto touch_block = [&](int bb) {
-        if constexpr (SWL_PA_L2_AHEAD > 0) {
-            if (bb < blk_end) {
-                const int64_t phys = bt[bb];
-                const T *src = (lane < 32 ? kc : vc) + (phys * blk_pitch + layer_head) * tile_elems + (lane & 31) * 64;
-                asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(src) : "memory");
-            }
-        }
     };
     // the first ND blocks of this wave go into slots 0..ND-1 (QKV: issued from inside the prologue)
     auto prefetch_kv = [&](int b0, auto lo_tag, auto hi_tag) {
@@ -576,9 +538,6 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
     // steady state: every refill is unconditional, so the waits between slots are exact counted vmcnt waits (a
     // conditional load in the body makes the compiler wait for one slot more than needed); slot d attends block
     // b + d*NW and is refilled with block b + (d+ND)*NW
-    constexpr int LA = SWL_PA_L2_AHEAD * ND;    // look-ahead distance in blocks of this wave
-#pragma unroll
-    for (int d = 0; d < LA; ++d) touch_block(b + (ND + d) * NW);
     if (b + (2 * ND - 1) * NW < blk_end) {
         // The first ND requests above are conditional (short sequence blocks), so on entry the compiler cannot know how
         // many loads are outstanding and would size EVERY wait of the loop for the fewest — i.e. wait for the newest
@@ -599,7 +558,6 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
             attend(b + d * NW, Kr[d], Vr[d]);
             __builtin_amdgcn_sched_barrier(0);
             load_phys(phys_next, Kr[d], Vr[d]);
-            touch_block(b + (d + ND + LA) * NW);
             __builtin_amdgcn_sched_barrier(0);
         }
         b += ND * NW;
@@ -618,7 +576,6 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_phase1_kernel(PagedAttnPar
 #pragma unroll
     for (int d = 0; d < ND - 1; ++d)
         if (b + (d + ND) * NW < blk_end) attend_tail(b + (d + ND) * NW, Kr[d], Vr[d]);
-    if constexpr (SWL_PA_L2_AHEAD > 0) asm volatile("" ::"v"(pf)); // the pinned register lives to here
 
     if constexpr (MF) {
         // O^T of the last block is stored by DS instructions below (swl_common.h)

@@ -8,6 +8,9 @@ reduction of per-rank counters — done over a `gloo` group on the host.
 """
 import datetime
 import os
+import socket
+import subprocess
+import sys
 from typing import List, Sequence, Tuple
 
 import torch
@@ -54,6 +57,56 @@ def init_control_group(timeout_s: int = 600) -> bool:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=timeout_s))
     return True
+
+
+def spawn_local_ranks(argv: Sequence[str], world_size: int, timeout_s: float = None, visible_devices=None) -> int:
+    """Launch `world_size` copies of the command `argv` on this node, one per GPU, with the environment a launcher
+    would give them (RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE, MASTER_ADDR=127.0.0.1, a free MASTER_PORT) and
+    rank i restricted to GPU i (HIP_VISIBLE_DEVICES=i, so every replica sees its device as "cuda:0" — the reference's
+    default-device convention, SURVEY.md §8e) unless the caller already restricted visibility. Rank 0 inherits stdout;
+    the other ranks' stdout goes to stderr. Returns the worst exit code; when one rank fails the rest are terminated.
+    What `bench.py --gpus N` uses when no torchrun environment is present."""
+    if world_size < 1:
+        raise ValueError("world_size must be >= 1")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    restricted = any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+    procs = []
+    for r in range(world_size):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world_size),
+                   LOCAL_WORLD_SIZE=str(world_size), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if visible_devices is not None:
+            env["HIP_VISIBLE_DEVICES"] = str(visible_devices[r])
+        elif not restricted:
+            env["HIP_VISIBLE_DEVICES"] = str(r)
+        procs.append(subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else sys.stderr))
+    worst = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                try:
+                    rc = p.wait(timeout=0.5)
+                except subprocess.TimeoutExpired:
+                    continue
+                pending.remove(p)
+                if rc != 0:
+                    worst = worst or rc
+                    for q in pending:       # a dead rank leaves the others waiting in a barrier for ever
+                        q.terminate()
+            if timeout_s is not None:
+                timeout_s -= 0.5 * max(1, len(pending))
+                if timeout_s <= 0 and pending:
+                    for q in pending:
+                        q.terminate()
+                    worst = worst or 124
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return worst
 
 
 def _parse_cpulist(text: str) -> List[int]:

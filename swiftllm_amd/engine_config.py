@@ -37,8 +37,10 @@ class EngineConfig:
     # One [h + 2*KVH*D, h] GEMM instead of three (the reference left this commented out,
     # weight.py:131). fuse_qkv=False + use_skinny_gemm=False reproduces the reference's exact BLAS calls.
     fuse_qkv: bool = True
-    # Capture pure-decode forwards into hipGraphs (one per batch size) and replay them.
-    use_hip_graph: bool = False
+    # Capture pure-decode forwards into hipGraphs (one per batch size and split-geometry bucket) and replay them: one
+    # graph launch per step instead of ~230 kernel launches (batch 32: 4.0 vs 4.35 ms/step on MI355X). The default;
+    # False (CLI: --no-hip-graph) launches every kernel from Python.
+    use_hip_graph: bool = True
     # Fused rotary + decode KV store (one launch instead of two) on pure-decode batches.
     fuse_rope_kvstore: bool = True
     # Route decode-sized projections (<= 32 tokens) to the hand-written weight-streaming MFMA GEMM
@@ -51,15 +53,11 @@ class EngineConfig:
     pack_decode_weights: bool = True
     # Pure-decode batches on the split-K path: rotary + KV store run in the paged-attention kernel's prologue.
     fuse_rope_into_attention: bool = True
-    # Decode batches of <= 32 sequences: fold residual-add / RMSNorm / rotary / KV-store into the projection
-    # GEMMs (5 launches per layer instead of 8). Parity-tested but OFF: on MI355X the in-kernel hand-off (slab
-    # write-through + device-scope count + last-arriver reduce) costs ~6 us per projection, as much as the
-    # kernel boundary it removes (139 vs 131 us per layer).
-    fuse_decode_layer: bool = False
     # Decode batches of <= 32 sequences: apply the RMSNorm scale AFTER the projection that consumes the normalised
     # activations (it is a per-token scalar), so the residual-add + norm split-K consumers become element-wise kernels
     # that fill the chip instead of one workgroup per token. Moves one rounding (the un-normalised
-    # activations are rounded, the scale is applied in fp32); needs hidden % 1024 == 0, else the exact path runs.
+    # activations are rounded, the scale is applied in fp32); bfloat16 only (float16's exponent range cannot hold the
+    # un-normalised intermediate safely: it keeps the reference's rounding points) and hidden % 1024 == 0.
     defer_rmsnorm: bool = True
     # Decode batches of <= 4 sequences: the qkv and up/gate projections sum the previous projection's split-K slabs
     # themselves (csrc/gemm_tiny.hip) — 5 launches per layer instead of 7. Needs defer_rmsnorm, packed weights, hidden <= 4096.
@@ -105,5 +103,7 @@ class EngineConfig:
                        help="Tokens per forward, at most")
         g.add_argument("--dtype", type=str, default="float16", choices=["float16", "bfloat16"])
         g.add_argument("--no-fuse-qkv", dest="fuse_qkv", action="store_false")
-        g.add_argument("--use-hip-graph", action="store_true")
+        g.add_argument("--use-hip-graph", dest="use_hip_graph", action="store_true", default=True,
+                       help="(default) replay captured hipGraphs for pure-decode steps")
+        g.add_argument("--no-hip-graph", dest="use_hip_graph", action="store_false")
         g.add_argument("--no-skinny-gemm", dest="use_skinny_gemm", action="store_false")

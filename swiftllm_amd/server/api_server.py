@@ -36,9 +36,11 @@ def _validate_body(body) -> "str | None":
     if ids is not None:
         if not isinstance(ids, list) or not all(isinstance(t, int) and not isinstance(t, bool) for t in ids):
             return "prompt_token_ids must be a list of integers"
+        if len(ids) == 0:
+            return "prompt_token_ids must not be empty"
         if any(t < 0 or t >= 2 ** 31 for t in ids):
             return "prompt_token_ids out of range"
-    elif not isinstance(body.get("prompt", ""), str):
+    if not isinstance(body.get("prompt", ""), str):    # also when token ids are given: the handler still touches it
         return "prompt must be a string"
     return None
 

@@ -90,13 +90,17 @@ def spawn_replicas(num: int, base_port: int, passthrough: List[str]) -> List[sub
     return procs
 
 
-async def wait_until_ready(urls: List[str], timeout_s: float = 1800.0) -> None:
-    """Poll every replica's GET /load until it answers (weights loaded, KV pool profiled)."""
+async def wait_until_ready(urls: List[str], timeout_s: float = 1800.0, procs=None) -> None:
+    """Poll every replica's GET /load until it answers (weights loaded, KV pool profiled). `procs` (the replicas'
+    subprocess.Popen objects, same order as `urls`): a replica whose process has exited fails the wait at once
+    instead of being polled until the timeout."""
     import aiohttp
     deadline = asyncio.get_event_loop().time() + timeout_s
     async with aiohttp.ClientSession(timeout=aiohttp.ClientTimeout(total=5)) as s:
-        for url in urls:
+        for i, url in enumerate(urls):
             while True:
+                if procs is not None and procs[i].poll() is not None:
+                    raise RuntimeError(f"replica {url} exited with code {procs[i].returncode} before it came up")
                 try:
                     async with s.get(url + "/load") as r:
                         if r.status == 200:
@@ -118,7 +122,7 @@ def main():
     router = ReplicaRouter([f"http://127.0.0.1:{args.port + 1 + i}" for i in range(args.num_replicas)])
     try:
         import uvicorn
-        asyncio.run(wait_until_ready(router.urls))      # accept traffic only when every replica can serve it
+        asyncio.run(wait_until_ready(router.urls, procs=procs))      # accept traffic only when every replica can serve it
         uvicorn.run(build_app(router), host=args.host, port=args.port, log_level="warning")
     finally:
         for p in procs:

@@ -304,87 +304,3 @@ def linear_silu_gate_from_splitk(partials, residual_in: torch.Tensor, residual_o
               _hip.ptr(residual_in), _hip.ptr(residual_out), _hip.ptr(norm_w), eps, _hip.ptr(_packed_of(w_up_gate)), m,
               inter, k, inter, _hip.dtype_code(partials.dtype), _hip.stream())
     return out
-
-
-# ---- fused decode layer (csrc/gemm_skinny.hip: "decode-layer fusion hooks") --------------------------------
-_MAX_NORM_K = 4096          # kMaxNormK: the normalising prologue keeps the norm weight of a K-chunk in LDS
-_fused_state = {}           # device -> (tile counters int64[4096], ssq fp32[1024 * 32]); fixed addresses
-
-
-class NormPending:
-    """The residual stream with its RMSNorm still pending: `residual` [M, hidden] already holds
-    x + residual, `ssq` [parts, 32] the per-128-column-tile sums of squares of its rows (left by the
-    epilogue of the projection that produced it). The next projection normalises on the fly."""
-    __slots__ = ("residual", "ssq", "parts")
-
-    def __init__(self, residual: torch.Tensor, ssq: torch.Tensor, parts: int):
-        self.residual, self.ssq, self.parts = residual, ssq, parts
-
-
-def _fused_buffers(device: torch.device):
-    st = _fused_state.get(device)
-    if st is None:
-        st = (torch.zeros(4096, dtype=torch.int64, device=device),
-              torch.zeros(1024 * 32, dtype=torch.float32, device=device))
-        _fused_state[device] = st
-    return st
-
-
-def fused_layer_ok(m: int, hidden: int, num_q_heads: int, num_kv_heads: int, head_dim: int, inter: int) -> bool:
-    """Shapes the fused decode layer covers (everything else takes the kernel-per-operator path)."""
-    n_qkv = (num_q_heads + 2 * num_kv_heads) * head_dim
-    return (0 < m <= _SKINNY_MAX_M and hidden % 128 == 0 and hidden <= _MAX_NORM_K and n_qkv % 128 == 0
-            and head_dim in (32, 64, 128) and inter % 128 == 0 and num_q_heads * head_dim % 128 == 0)
-
-
-def linear_add_residual(a: torch.Tensor, w: torch.Tensor, residual: torch.Tensor) -> NormPending:
-    """residual += a @ w^T (rounded like linear + fused_add_rmsnorm's add); returns the stream with its norm
-    pending. One launch: the split-K reduce and the residual add run in the GEMM's last-arriving workgroups."""
-    m, k = a.shape
-    n = w.shape[0]
-    assert residual.shape == (m, n) and residual.is_contiguous() and residual.dtype == a.dtype == w.dtype
-    counters, ssq = _fused_buffers(a.device)
-    ks = max(1, _hip.load().swl_gemm_skinny_choose_splits(n, k))
-    ws = _workspace(a.device, ks * m * n * 4)
-    _hip.call("swl_gemm_skinny_add_residual", _hip.ptr(residual), _hip.ptr(ssq), _hip.ptr(a), _hip.ptr(w),
-              _hip.ptr(ws), ws.numel() * 4, _hip.ptr(counters), counters.numel(), m, n, k, _row_stride(a),
-              _hip.dtype_code(a.dtype), _hip.stream())
-    return NormPending(residual, ssq, n // 128)
-
-
-def linear_norm_silu_gate(x: NormPending, norm_w: torch.Tensor, eps: float, w_up_gate: torch.Tensor) -> torch.Tensor:
-    """silu_gate(rmsnorm(x.residual) @ [up ; gate]^T) in one launch."""
-    m, k = x.residual.shape
-    inter = w_up_gate.shape[0] // 2
-    out = torch.empty((m, inter), dtype=x.residual.dtype, device=x.residual.device)
-    _hip.call("swl_gemm_skinny_norm_silu_gate", _hip.ptr(out), _hip.ptr(x.residual), _hip.ptr(x.ssq), x.parts,
-              _hip.ptr(norm_w), eps, _hip.ptr(w_up_gate), m, inter, k, k, inter, _hip.dtype_code(out.dtype),
-              _hip.stream())
-    return out
-
-
-def linear_qkv_rope_store(x, norm_w: torch.Tensor, eps: float, w_qkv: torch.Tensor, k_cache: torch.Tensor,
-                          v_cache: torch.Tensor, block_table: torch.Tensor, model_config, engine_config,
-                          infer_state, cur_layer: int) -> torch.Tensor:
-    """The fused qkv projection of a decode batch with rotary + KV-store in its epilogue. `x` is either an
-    already normalised [M, hidden] tensor or a NormPending stream (then the attention norm is applied on the
-    fly). Returns the rotated q [M, H, D]; rotated k and v are in the pools."""
-    pending = isinstance(x, NormPending)
-    a = x.residual if pending else x
-    m, k = a.shape
-    h, kvh, d = model_config.num_q_heads, model_config.num_kv_heads, model_config.head_dim
-    n = (h + 2 * kvh) * d
-    assert w_qkv.shape == (n, k) and infer_state.position_indices is not None and m == infer_state.num_decoding_seqs
-    counters, _ = _fused_buffers(a.device)
-    ks = max(1, _hip.load().swl_gemm_skinny_choose_splits(n, k))
-    ws = _workspace(a.device, ks * m * n * 4)
-    q = torch.empty((m, h, d), dtype=a.dtype, device=a.device)
-    _hip.call("swl_gemm_skinny_qkv_rope_store", _hip.ptr(q), _hip.ptr(a), _hip.ptr(x.ssq) if pending else None,
-              x.parts if pending else 0, _hip.ptr(norm_w) if pending else None, eps, _hip.ptr(w_qkv), _hip.ptr(ws),
-              ws.numel() * 4, _hip.ptr(counters), counters.numel(), _hip.ptr(infer_state.position_cos),
-              _hip.ptr(infer_state.position_sin), _hip.ptr(infer_state.position_indices), _hip.ptr(k_cache),
-              _hip.ptr(v_cache), _hip.ptr(block_table), _hip.ptr(infer_state.seq_ids),
-              _hip.ptr(infer_state.decoding_seq_lens), m, h, kvh, d, k, cur_layer, model_config.num_layers,
-              engine_config.block_size, block_table.shape[1], h * d, _row_stride(a), _hip.dtype_code(a.dtype),
-              _hip.stream())
-    return q

@@ -65,8 +65,14 @@ class RowScalePending:
         self.hidden = hidden or (x.shape[1] if x is not None else 0)
 
 
-def deferred_norm_ok(num_tokens: int, hidden: int) -> bool:
-    return 0 < num_tokens <= 32 and hidden % _ADD_SCALE_CHUNK == 0 and hidden // _ADD_SCALE_CHUNK <= _MAX_SSQ_PARTS
+def deferred_norm_ok(num_tokens: int, hidden: int, dtype: torch.dtype = torch.bfloat16) -> bool:
+    """bfloat16 only: the deferred form stores round(residual * norm_weight) BEFORE the 1/rms is applied. bfloat16 has
+    fp32's exponent range, so that intermediate can neither overflow nor go subnormal; in float16 a residual outlier of
+    1e4 times a norm weight of 3 is already at 3e4 of 65504, and rows with rms << 1 would lose bits to subnormals —
+    neither can happen on the reference's path (rmsnorm.py:59-64 rounds x * rstd * w once). float16 therefore keeps the
+    reference's rounding points (fused_add_rmsnorm_from_splitk)."""
+    return (dtype == torch.bfloat16 and 0 < num_tokens <= 32 and hidden % _ADD_SCALE_CHUNK == 0
+            and hidden // _ADD_SCALE_CHUNK <= _MAX_SSQ_PARTS)
 
 
 def add_scale_from_splitk(partials, residual_io: torch.Tensor, weight: torch.Tensor, eps: float) -> RowScalePending:
@@ -76,7 +82,7 @@ def add_scale_from_splitk(partials, residual_io: torch.Tensor, weight: torch.Ten
     m, n = partials.shape
     _check_rows(residual_io, "residual_io")
     assert residual_io.shape == (m, n) and residual_io.dtype == partials.dtype == weight.dtype
-    assert deferred_norm_ok(m, n)
+    assert deferred_norm_ok(m, n)      # (shape limits; the bfloat16-only POLICY is the caller's: transformer_layer.py)
     parts = n // _ADD_SCALE_CHUNK
     xs = torch.empty((m, n), dtype=partials.dtype, device=residual_io.device)
     ssq = torch.empty((parts, m), dtype=torch.float32, device=residual_io.device)

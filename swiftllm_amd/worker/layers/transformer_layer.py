@@ -13,7 +13,7 @@ partial slabs (SplitKPartials) straight to the next kernel — fused qkv -> rota
 o_proj -> the FFN's fused_add_rmsnorm, down_proj -> the NEXT layer's fused_add_rmsnorm — so `forward`
 may return, and accept, a SplitKPartials in place of the activation tensor.
 
-Deferred RMSNorm (defer_rmsnorm, batches of <= 32 sequences, hidden % 1024 == 0): the residual-add + norm consumers of
+Deferred RMSNorm (defer_rmsnorm, bfloat16 only, batches of <= 32 sequences, hidden % 1024 == 0): the residual-add + norm consumers of
 the o_proj / down_proj slabs only do the element-wise part, in a launch that fills the chip (add_scale_from_splitk);
 the per-token 1/rms is applied by the consumer of the normalised activations — the slab-fed attention prologue for the
 qkv projection, the SiLU-gate GEMM's epilogue for the FFN — in fp32, before its one rounding.
@@ -22,24 +22,17 @@ Very small decode batches (tiny_decode_batches, <= 4 sequences): the two consume
 qkv projection and the up/gate projection sum the previous projection's slabs themselves while their first weight
 tiles are in flight (kernels/linear.py: linear_splitk_from_splitk / linear_silu_gate_from_splitk, csrc/gemm_tiny.hip),
 the residual stream ping-pongs between two buffers: 5 launches per layer instead of 7.
-
-Fused decode layer (fuse_decode_layer, batches of <= 32 sequences): the hand-offs themselves move into the
-GEMMs — qkv projection (+ attention norm on the fly) with rotary/KV-store in its epilogue, attention,
-o_proj with the residual add in its epilogue, up/gate (+ FFN norm on the fly) with SiLU-gate, down_proj with
-the residual add: 5 launches per layer instead of 8. The layer then returns a NormPending (the residual
-stream already holds the sum; its RMSNorm is applied by whoever consumes it).
 """
 import torch
 
-from ..kernels.linear import (NormPending, SplitKPartials, fused_layer_ok, linear, linear_add_residual,
-                              linear_norm_silu_gate, linear_qkv_rope_store, linear_silu_gate, linear_splitk)
+from ..kernels.linear import SplitKPartials, linear, linear_silu_gate, linear_splitk
 from ..kernels.linear import _TINY_POLICY_M as TINY_POLICY_M
 from ..kernels.linear import attn_partials_ok, linear_splitk_from_attn_partials
 from ..kernels.linear import (row_scaled_silu_gate_ok, alt_residual_like, linear_silu_gate_from_splitk,
                               linear_splitk_from_splitk, tiny_from_splitk_ok)
 from ..kernels.rmsnorm import RowScalePending
 from ..kernels.rmsnorm import (add_scale_from_splitk, deferred_norm_ok, fused_add_rmsnorm_inplace,
-                               fused_add_rmsnorm_from_splitk, rmsnorm_inplace)
+                               fused_add_rmsnorm_from_splitk)
 from ..kernels.rotary_emb import (rotary_embedding_inplace, rotary_embedding_and_store_kvcache_decode,
                                   rotary_embedding_and_store_kvcache_decode_from_splitk)
 from ..kernels.kvcache_mgmt import store_kvcache
@@ -80,12 +73,6 @@ class LlamaTransformerLayer:
                 v_cache: torch.Tensor, block_table: torch.Tensor, infer_state):
         cfg, ecfg, w, st = self.model_config, self.engine_config, self.weight, infer_state
 
-        if self._fused_decode_applies(st, residual_buf):
-            return self._forward_decode_fused(input_embds, residual_buf, k_cache, v_cache, block_table, st)
-        if isinstance(input_embds, NormPending):    # (a fused layer followed by an unfused one: same stream)
-            input_embds = self._materialize_norm(input_embds, w.attn_norm)
-            return self._forward_after_attn_norm(input_embds, residual_buf, k_cache, v_cache, block_table, st)
-
         # residual_buf <- input_embds + residual_buf ; input_embds <- rmsnorm(residual_buf)
         row_scale = None
         if isinstance(input_embds, SplitKPartials):     # the previous layer's down projection, unreduced
@@ -113,7 +100,7 @@ class LlamaTransformerLayer:
         """The attention norm's 1/rms can be left to the attention prologue: slab-fed attention with <= 4 qkv slabs."""
         cfg, ecfg, w = self.model_config, self.engine_config, self.weight
         if not (getattr(ecfg, "defer_rmsnorm", False) and self._slab_fed_attention_applies(st)
-                and deferred_norm_ok(st.num_decoding_seqs, cfg.hidden_size)):
+                and deferred_norm_ok(st.num_decoding_seqs, cfg.hidden_size, w.qkv_proj.dtype)):
             return False
         if self._qkv_splits is None:
             from swiftllm_amd import _hip
@@ -164,37 +151,6 @@ class LlamaTransformerLayer:
         # alt + o_proj slabs -> residual_buf ; up * silu(gate) of rmsnorm(residual_buf)
         act = linear_silu_gate_from_splitk(attn_out, alt, residual_buf, w.ffn_norm, eps, w.up_gate_proj)
         return linear_splitk(act, w.down_proj)
-
-    def _fused_decode_applies(self, st, residual_buf) -> bool:
-        cfg, ecfg, w = self.model_config, self.engine_config, self.weight
-        return (self.skinny and getattr(ecfg, "fuse_decode_layer", False) and w.qkv_proj is not None
-                and st.num_prefill_seqs == 0 and st.num_decoding_seqs > 0 and not st.ignore_kvcache
-                and st.position_indices is not None and residual_buf.is_contiguous()
-                and fused_layer_ok(st.num_decoding_seqs, cfg.hidden_size, cfg.num_q_heads, cfg.num_kv_heads,
-                                   cfg.head_dim, cfg.ffn_inter_dim))
-
-    def _materialize_norm(self, pending: NormPending, norm_w: torch.Tensor) -> torch.Tensor:
-        x = pending.residual.clone()
-        rmsnorm_inplace(x, norm_w, self.model_config.rms_norm_eps)
-        return x
-
-    def _forward_decode_fused(self, input_embds, residual_buf, k_cache, v_cache, block_table, st):
-        cfg, ecfg, w = self.model_config, self.engine_config, self.weight
-        eps = cfg.rms_norm_eps
-        if not isinstance(input_embds, NormPending):
-            # first layer (or after an unfused one): the ordinary add + norm, then the projection as it is
-            if isinstance(input_embds, SplitKPartials):
-                input_embds = fused_add_rmsnorm_from_splitk(input_embds, residual_buf, w.attn_norm, eps)
-            else:
-                fused_add_rmsnorm_inplace(input_embds, residual_buf, w.attn_norm, eps)
-        q = linear_qkv_rope_store(input_embds, w.attn_norm, eps, w.qkv_proj, k_cache, v_cache, block_table, cfg,
-                                  ecfg, st, self.layer_id)
-        o = torch.empty_like(residual_buf)
-        paged_attention(q, k_cache, v_cache, block_table, cfg, ecfg, st, self.layer_id,
-                        o.view(-1, cfg.num_q_heads, cfg.head_dim))
-        stream = linear_add_residual(o, w.o_proj, residual_buf)
-        act = linear_norm_silu_gate(stream, w.ffn_norm, eps, w.up_gate_proj)
-        return linear_add_residual(act, w.down_proj, residual_buf)
 
     def _forward_after_attn_norm(self, input_embds, residual_buf, k_cache, v_cache, block_table, infer_state,
                                  row_scale=None):
@@ -263,7 +219,8 @@ class LlamaTransformerLayer:
         if fast:
             attn_out = linear_splitk(input_embds, w.o_proj)
             if isinstance(attn_out, SplitKPartials):
-                if (getattr(self.engine_config, "defer_rmsnorm", False) and deferred_norm_ok(*attn_out.shape)
+                if (getattr(self.engine_config, "defer_rmsnorm", False)
+                        and deferred_norm_ok(*attn_out.shape, attn_out.dtype)
                         and row_scaled_silu_gate_ok(input_embds, w.up_gate_proj)):
                     # element-wise add + scale (fills the chip); the FFN norm's 1/rms goes into the SiLU-gate GEMM
                     pend = add_scale_from_splitk(attn_out, residual_buf, w.ffn_norm, cfg.rms_norm_eps)

@@ -34,7 +34,6 @@ from .batch_plan import BatchPlan, plan_batch
 from .block_manager import BlockManager
 from .infer_state import LlamaInferState
 from .kernels.block_swapping import swap_blocks
-from .kernels.linear import NormPending
 from .kernels.rmsnorm import fused_add_rmsnorm_from_splitk
 from .layers.pre_layer import LlamaPreLayer
 from .layers.transformer_layer import LlamaTransformerLayer
@@ -85,6 +84,7 @@ class LlamaModel:
         self._meta_done = None
         self._num_slots = 256        # CUs: one 8-wave paged-attention workgroup each
         self._decode_graphs = {}     # (batch, split width, split count) -> _DecodeGraph, in LRU order
+        self._eager_uses_graph_buckets = False   # tests: eager launches at the replay path's split geometry
         self._graph_pool = None
         self._scratch = None
 
@@ -261,8 +261,6 @@ class LlamaModel:
         block_table = None if infer_state.ignore_kvcache else self.gpu_block_manager.block_table
         for layer in self.transformer_layers:
             x = layer.forward(x, residual, self.k_cache, self.v_cache, block_table, infer_state)
-        if isinstance(x, NormPending):          # fused decode layers: the stream already holds x + residual
-            return self.post_layer.forward(x.residual, infer_state)
         if not isinstance(x, torch.Tensor):     # the last down projection left as split-K partials
             if infer_state.num_prefill_seqs == 0:
                 # pure decode: every row is a last token — reduce + residual add + final norm in one launch
@@ -352,6 +350,8 @@ class LlamaModel:
         if (pure_decode and not ignore_kvcache and getattr(self.engine_config, "use_hip_graph", False)):
             tokens = self._forward_decode_graph(plan, dev)
         else:
+            if pure_decode and not ignore_kvcache and self._eager_uses_graph_buckets:
+                plan.seq_block_size, plan.num_seq_blocks = self._graph_bucket(plan)
             tokens = self._forward(dev["input_ids"], self._make_infer_state(plan, dev, ignore_kvcache))
         return tokens.tolist()
 

@@ -97,8 +97,7 @@ def test_split_heuristics_are_host_side_and_stable():
 
 
 def test_split_choosers_are_host_functions_with_the_documented_values():
-    """swl_gemm_skinny_choose_splits / swl_gemm_skinny_packed_choose_splits / swl_gemm_wgk_supported /
-    swl_gemm_tiny_max_tokens need no device: the values the Python layer (and DESIGN.md section 4.3) relies on."""
+    """swl_gemm_skinny_choose_splits / swl_gemm_skinny_packed_choose_splits / swl_gemm_tiny_max_tokens need no device: the values the Python layer (and DESIGN.md section 4.3) relies on."""
     from swiftllm_amd import _hip
     lib = _hip.load()
     even, packed = lib.swl_gemm_skinny_choose_splits, lib.swl_gemm_skinny_packed_choose_splits
@@ -117,6 +116,4 @@ def test_split_choosers_are_host_functions_with_the_documented_values():
             if k % (128 * p):
                 assert kt // p >= 8
     assert even(100, 4096) == 0 and packed(4096, 100) == 0          # N % 32, K % 128
-    assert lib.swl_gemm_wgk_supported(32, 4096, 4096) == 1 and lib.swl_gemm_wgk_supported(33, 4096, 4096) == 0
-    assert lib.swl_gemm_wgk_supported(8, 4096, 11008) == 0          # K % 1024
     assert lib.swl_gemm_tiny_max_tokens() == 4

@@ -85,3 +85,35 @@ def test_replica_core_sets_are_disjoint_and_cover_the_allowed_cores():
         if world > 1:
             assert len(flat) == len(set(flat))
     assert _dp._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+
+
+def test_spawn_local_ranks_gives_every_rank_its_gpu_and_a_working_control_group(tmp_path, capfd):
+    """What `bench.py --gpus N` does without a launcher (dp.spawn_local_ranks): N processes with the torchrun
+    environment, rank i pinned to GPU i, a gloo control group that works, rank 0's stdout passed through, the worst
+    exit code returned."""
+    import sys
+    import textwrap
+    script = tmp_path / "rank.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        from swiftllm_amd import dp
+        rank, local_rank, world = dp.env_rank_world()
+        assert dp.init_control_group(timeout_s=60)
+        units, secs = dp.reduce_job(10 * (rank + 1), 1.0 + rank)
+        dp.barrier()
+        print("RANK", rank, world, os.environ["HIP_VISIBLE_DEVICES"], os.environ["LOCAL_WORLD_SIZE"], units, secs, flush=True)
+        sys.exit(int(os.environ.get("FAIL_RANK", "-1")) == rank)
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    env_keys = ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "WORLD_SIZE", "RANK")
+    saved = {k: os.environ.pop(k) for k in env_keys if k in os.environ}
+    try:
+        assert dp.spawn_local_ranks([sys.executable, str(script)], 2, timeout_s=120) == 0
+        out, err = capfd.readouterr()
+        assert "RANK 0 2 0 2 30.0 2.0" in out and "RANK 1" not in out      # rank 0 owns stdout
+        assert "RANK 1 2 1 2 30.0 2.0" in err
+        os.environ["FAIL_RANK"] = "1"
+        assert dp.spawn_local_ranks([sys.executable, str(script)], 2, timeout_s=120) == 1
+    finally:
+        os.environ.pop("FAIL_RANK", None)
+        os.environ.update(saved)

@@ -643,111 +643,6 @@ def test_argmax_rows_matches_torch_with_lowest_index_ties(dtype, rows, n):
     assert argmax_rows(neg).tolist() == [0, 0]
 
 
-# ---- fused decode layer: projections with the hand-offs folded in ---------------------------------------
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,Kd", [(32, 4096, 4096), (32, 4096, 14336), (5, 128, 128), (7, 512, 1024),
-                                    (32, 256, 2048 + 128), (1, 1024, 512)])
-def test_gemm_add_residual_epilogue(dtype, M, N, Kd):
-    """residual bits == skinny linear followed by fused_add_rmsnorm's add; per-tile sums of squares exact to
-    fp32 rounding; the tile counters are left clean (a second launch gives the same bits)."""
-    from swiftllm_amd.worker.kernels.linear import linear_add_residual
-    g = gen(M + N + Kd)
-    x = torch.randn(M, Kd, generator=g).to(dtype).cuda()
-    w = (torch.randn(N, Kd, generator=g) * 0.02).to(dtype).cuda()
-    res0 = torch.randn(M, N, generator=g).to(dtype).cuda()
-    nw = torch.ones(N, dtype=dtype, device="cuda")
-    want = res0.clone()
-    K().fused_add_rmsnorm_inplace(K().linear(x, w, skinny=True), want, nw, 1e-5)
-    for _ in range(2):
-        got = res0.clone()
-        pending = linear_add_residual(x, w, got)
-        assert torch.equal(got, want)
-        assert pending.parts == N // 128
-        ssq = pending.ssq[:pending.parts * 32].view(pending.parts, 32)[:, :M].double().cpu()
-        ref = want.double().cpu().view(M, N // 128, 128).pow(2).sum(-1).T
-        assert torch.allclose(ssq, ref, rtol=1e-5, atol=1e-6)
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,I,Kd", [(32, 14336, 4096), (7, 256, 128), (9, 96, 1152), (32, 1024, 512)])
-def test_gemm_norm_silu_gate_prologue(dtype, M, I, Kd):
-    """rmsnorm on the fly == rmsnorm kernel then the SiLU-gate GEMM (1/rms is summed in a different order:
-    identical up to rare one-ulp flips of the normalised activations)."""
-    from swiftllm_amd.worker.kernels.linear import linear_add_residual, linear_norm_silu_gate, linear_silu_gate
-    g = gen(M + I + Kd)
-    x = torch.randn(M, 256, generator=g).to(dtype).cuda()
-    wo = (torch.randn(Kd, 256, generator=g) * 0.05).to(dtype).cuda()
-    res = torch.randn(M, Kd, generator=g).to(dtype).cuda()
-    nw = (1 + 0.1 * torch.randn(Kd, generator=g)).to(dtype).cuda()
-    w = (torch.randn(2 * I, Kd, generator=g) * 0.03).to(dtype).cuda()
-    pending = linear_add_residual(x, wo, res)          # leaves res updated + its sums of squares
-    got = linear_norm_silu_gate(pending, nw, 1e-5, w)
-    normed = res.clone()
-    K().rmsnorm_inplace(normed, nw, 1e-5)
-    want = linear_silu_gate(normed, w)
-    eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
-    diff = (got.float() - want.float()).abs()
-    assert (diff <= 4 * eps * want.float().abs() + 1e-3).all()
-    assert (diff > 0).float().mean() < 0.05             # the overwhelming majority is bit-identical
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("H,KVH,D,hid", [(32, 8, 128, 4096), (4, 2, 32, 128), (4, 2, 64, 256), (4, 1, 128, 512)])
-@pytest.mark.parametrize("pending_norm", [False, True])
-def test_gemm_qkv_rope_store_epilogue(dtype, H, KVH, D, hid, pending_norm):
-    """qkv projection with rotary + KV-store in the epilogue == split-K projection, then the rotary+store kernel:
-    q and both pools bit-identical when x comes normalised; close when the norm is applied on the fly."""
-    from swiftllm_amd.worker.kernels.linear import (NormPending, linear_add_residual, linear_qkv_rope_store)
-    from swiftllm_amd.worker.kernels.rotary_emb import rotary_embedding_and_store_kvcache_decode
-    g = gen(H * 7 + D + hid)
-    L, layer, nd = 2, 1, 7
-    n = (H + 2 * KVH) * D
-    wqkv = (torch.randn(n, hid, generator=g) * 0.03).to(dtype).cuda()
-    lens = [1, 16, 17, 33, 100, 64, 5]
-    seq_ids = [3, 0, 6, 1, 2, 5, 4]
-    need = [-(-v // 16) for v in lens]
-    perm = torch.randperm(sum(need) + 2, generator=g).tolist()
-    bt = torch.zeros(8, 16, dtype=torch.int32)
-    for sid, c in zip(seq_ids, need):
-        for j in range(c):
-            bt[sid, j] = perm.pop()
-    bt = bt.cuda()
-    ang = torch.rand(128, D // 2, generator=g) * 6.28
-    st = NS(num_prefill_seqs=0, num_decoding_seqs=nd, position_cos=torch.cos(ang).to(dtype).cuda(),
-            position_sin=torch.sin(ang).to(dtype).cuda(),
-            position_indices=torch.tensor([v - 1 for v in lens], dtype=torch.int32, device="cuda"),
-            seq_ids=torch.tensor(seq_ids, dtype=torch.int32, device="cuda"),
-            decoding_seq_lens=torch.tensor(lens, dtype=torch.int32, device="cuda"))
-    mc, ec = NS(num_q_heads=H, num_kv_heads=KVH, head_dim=D, num_layers=L), NS(block_size=16)
-    shape = (sum(need) + 2, L, KVH, 16, D)
-    nw = (1 + 0.1 * torch.randn(hid, generator=g)).to(dtype).cuda()
-    if pending_norm:
-        xa = torch.randn(nd, 128, generator=g).to(dtype).cuda()
-        wa = (torch.randn(hid, 128, generator=g) * 0.05).to(dtype).cuda()
-        res = torch.randn(nd, hid, generator=g).to(dtype).cuda()
-        x_in = linear_add_residual(xa, wa, res)
-        x = res.clone()
-        K().rmsnorm_inplace(x, nw, 1e-5)
-    else:
-        x = torch.randn(nd, hid, generator=g).to(dtype).cuda()
-        x_in = x
-    qkv = K().linear(x, wqkv, skinny=True)
-    q1 = qkv[:, :H * D].view(nd, H, D)
-    k1 = qkv[:, H * D:(H + KVH) * D].view(nd, KVH, D)
-    v1 = qkv[:, (H + KVH) * D:].view(nd, KVH, D)
-    kc1, vc1 = torch.zeros(shape, dtype=dtype, device="cuda"), torch.zeros(shape, dtype=dtype, device="cuda")
-    rotary_embedding_and_store_kvcache_decode(q1, k1, v1, kc1, vc1, bt, mc, ec, st, layer)
-    for _ in range(2):
-        kc2, vc2 = torch.zeros_like(kc1), torch.zeros_like(vc1)
-        q2 = linear_qkv_rope_store(x_in, nw, 1e-5, wqkv, kc2, vc2, bt, mc, ec, st, layer)
-        if pending_norm:
-            eps = 2.0 ** -9 if dtype == torch.float16 else 2.0 ** -6
-            for a, b in ((q2, q1), (kc2, kc1), (vc2, vc1)):
-                assert ((a.float() - b.float()).abs() <= eps * b.float().abs() + 2e-3).all()
-        else:
-            assert torch.equal(q2, q1) and torch.equal(kc2, kc1) and torch.equal(vc2, vc1)
-
-
 # ---- paged attention with rotary + KV store in its prologue ------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("sbs", [64, 1024])      # several splits (only the last owns the new token) / one split
@@ -1056,67 +951,6 @@ def test_tiny_batch_projections_equal_consumer_plus_gemm(dtype, M, hid, N, inter
     ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
     err = (act_new.float() - act_ref.float()).abs()
     assert (err <= 4 * ulp * act_ref.float().abs() + 1e-5).all(), err.max().item()
-
-
-# ---- projections with K split inside the workgroup (gemm_wgk.hip) --------------------------------------------------------
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M", [1, 7, 32])
-@pytest.mark.parametrize("N,K", [(4096, 4096), (6144, 4096), (4096, 14336), (256, 1024), (96, 3072)])
-def test_in_workgroup_split_k_projection(dtype, M, N, K):
-    """swl_gemm_wgk / swl_gemm_wgk_add_scale: the direct output against an fp64 product (and, rounded, against the
-    split-K kernel's 8-slab sum — same K partition, same order, hence the same bits); the add+scale epilogue against
-    swl_gemm_skinny_packed_partial (8 splits) + swl_splitk_add_scale bit for bit on residual and x_scaled, sums of squares
-    to fp32 rounding; the deferred 1/rms against the scaled product."""
-    from swiftllm_amd import _hip
-    lib = _hip.load()
-    if not lib.swl_gemm_wgk_supported(M, N, K):
-        pytest.skip("shape outside the kernel's limits")
-    g = gen(N + K + M)
-    code = _hip.dtype_code(dtype)
-    x = torch.randn(M, K, generator=g).to(dtype).cuda()
-    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dtype).cuda()
-    wp = torch.empty_like(w)
-    _hip.call("swl_gemm_pack_weight", wp.data_ptr(), w.data_ptr(), N, K, code, _hip.stream())
-    ref = x.double().cpu() @ w.double().cpu().t()
-    # direct, fp32 out
-    o32 = torch.empty(M, N, dtype=torch.float32, device="cuda")
-    _hip.call("swl_gemm_wgk", o32.data_ptr(), 1, x.data_ptr(), wp.data_ptr(), None, 0, 0, 0.0, M, N, K, K, N, code,
-              _hip.stream())
-    assert (o32.double().cpu() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
-    # direct, storage dtype == the split-K kernel with 8 slabs, reduced
-    oT = torch.empty(M, N, dtype=dtype, device="cuda")
-    _hip.call("swl_gemm_wgk", oT.data_ptr(), 0, x.data_ptr(), wp.data_ptr(), None, 0, 0, 0.0, M, N, K, K, N, code,
-              _hip.stream())
-    ws = torch.empty(16 * M * N, dtype=torch.float32, device="cuda")
-    o8 = torch.empty(M, N, dtype=dtype, device="cuda")
-    _hip.call("swl_gemm_skinny_packed", o8.data_ptr(), x.data_ptr(), wp.data_ptr(), ws.data_ptr(), ws.numel() * 4, M, N, K,
-              K, N, 8, code, _hip.stream())
-    assert torch.equal(oT, o8)
-    # deferred 1/rms of the input rows
-    ssq = (torch.rand(4, M, generator=g) * K / 4 + 0.1).float().cuda()
-    oS = torch.empty(M, N, dtype=torch.float32, device="cuda")
-    _hip.call("swl_gemm_wgk", oS.data_ptr(), 1, x.data_ptr(), wp.data_ptr(), ssq.data_ptr(), 4, M, 1e-5, M, N, K, K, N,
-              code, _hip.stream())
-    rs = 1.0 / torch.sqrt(ssq.sum(0) / K + 1e-5)
-    assert torch.allclose(oS, o32 * rs[:, None], rtol=3e-6, atol=1e-7)
-    if N % 1024:
-        return      # swl_splitk_add_scale groups its sums of squares by 1024 columns
-    # add + scale epilogue
-    nw = (1 + 0.1 * torch.randn(N, generator=g)).to(dtype).cuda()
-    res0 = torch.randn(M, N, generator=g).to(dtype).cuda()
-    r_old, r_new = res0.clone(), res0.clone()
-    xs_old, xs_new = torch.empty_like(res0), torch.empty_like(res0)
-    ssq_old = torch.zeros(N // 1024, M, dtype=torch.float32, device="cuda")
-    ssq_new = torch.zeros(N // 32, 32, dtype=torch.float32, device="cuda")
-    _hip.call("swl_gemm_skinny_packed_partial", ws.data_ptr(), ws.numel() * 4, x.data_ptr(), wp.data_ptr(), M, N, K, K, 8,
-              code, _hip.stream())
-    _hip.call("swl_splitk_add_scale", xs_old.data_ptr(), r_old.data_ptr(), nw.data_ptr(), ws.data_ptr(), 8,
-              ssq_old.data_ptr(), M, N, code, _hip.stream())
-    _hip.call("swl_gemm_wgk_add_scale", xs_new.data_ptr(), r_new.data_ptr(), ssq_new.data_ptr(), nw.data_ptr(),
-              x.data_ptr(), wp.data_ptr(), M, N, K, K, code, _hip.stream())
-    assert torch.equal(r_new, r_old) and torch.equal(xs_new, xs_old)
-    so, sn = ssq_old.sum(0), ssq_new[:, :M].sum(0)
-    assert ((so - sn).abs() <= 2e-6 * so).all()
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -192,7 +192,7 @@ def test_engine_config_is_field_compatible_with_the_reference():
     ec = EngineConfig(model_path="/x", use_dummy=False, block_size=16, gpu_mem_utilization=0.99,
                       num_cpu_blocks=0, max_seqs_in_block_table=128, max_blocks_per_seq=2048,
                       max_batch_size=16, max_tokens_in_batch=2048 * 16)
-    assert ec.dtype == "float16" and ec.fuse_qkv is True and ec.use_hip_graph is False
+    assert ec.dtype == "float16" and ec.fuse_qkv is True and ec.use_hip_graph is True
     import argparse
     p = argparse.ArgumentParser()
     EngineConfig.add_cli_args(p)

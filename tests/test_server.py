@@ -196,13 +196,30 @@ def test_api_server_generate_endpoint():
         for body in ({"prompt_token_ids": [1, 2]}, {"prompt_token_ids": [1, 2], "output_len": "3"},
                      {"prompt_token_ids": [1, "x"], "output_len": 3}, {"prompt_token_ids": [1, -5], "output_len": 3},
                      {"prompt_token_ids": [1, 2 ** 40], "output_len": 3}, {"prompt_token_ids": "12", "output_len": 3},
-                     {"prompt": 17, "output_len": 3}, [1, 2, 3]):
+                     {"prompt": 17, "output_len": 3}, [1, 2, 3],
+                     {"prompt_token_ids": [], "prompt": 5, "output_len": 1},          # (was a 500)
+                     {"prompt_token_ids": [1, 2], "prompt": 5, "output_len": 1}, {"prompt_token_ids": [], "output_len": 1}):
             r = client.post("/generate", json=body)
             assert r.status_code == 400 and "error" in r.json(), body
         r = client.post("/generate", content=b"{not json", headers={"content-type": "application/json"})
         assert r.status_code == 400
         r = client.post("/generate", json={"prompt_token_ids": [4, 5], "output_len": 3})
         assert r.status_code == 200 and r.json() == {"output_token_ids": _expected([4, 5], 3)}  # still alive
+
+
+def test_wait_until_ready_fails_fast_when_a_replica_process_is_dead():
+    """router.wait_until_ready polls GET /load; a replica whose process already exited must fail the wait at once,
+    not after the 30-minute timeout."""
+    import subprocess
+    import sys
+    import time
+    from swiftllm_amd.server.router import wait_until_ready
+    dead = subprocess.Popen([sys.executable, "-c", "import sys; sys.exit(3)"])
+    dead.wait()
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match="exited with code 3"):
+        asyncio.run(wait_until_ready(["http://127.0.0.1:9"], timeout_s=600, procs=[dead]))
+    assert time.time() - t0 < 30
 
 
 def test_replica_router_balances_by_outstanding_tokens():

@@ -61,6 +61,62 @@ def make_state_dict(cfg: dict, seed: int = 0, dtype=torch.float16, std: float = 
     return sd
 
 
+def make_state_dict_on_gpu(cfg: dict, seed: int = 0, dtype=torch.float16, std: float = 0.02, lm_head_std: float = None) -> dict:
+    """make_state_dict for full-size models (Llama-3-8B: 8 G parameters): the same tensor names, shapes and
+    distributions, drawn on the GPU (a CPU generator needs minutes for 16 GB) and returned as CPU tensors. NOT the
+    same values as make_state_dict(seed): both sides of a comparison must load the file this dict is written to."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    h, inter, v = cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"]
+    kv = cfg.get("num_key_value_heads", cfg["num_attention_heads"]) * (h // cfg["num_attention_heads"])
+
+    def mat(*shape, s=std):
+        return (torch.randn(*shape, generator=g, device="cuda") * s).to(dtype).cpu()
+
+    def norm(n):
+        return (1.0 + torch.randn(n, generator=g, device="cuda") * std).to(dtype).cpu()
+
+    sd = {"model.embed_tokens.weight": mat(v, h), "lm_head.weight": mat(v, h, s=lm_head_std or std),
+          "model.norm.weight": norm(h)}
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"model.layers.{i}."
+        sd[p + "input_layernorm.weight"] = norm(h)
+        sd[p + "self_attn.q_proj.weight"] = mat(h, h)
+        sd[p + "self_attn.k_proj.weight"] = mat(kv, h)
+        sd[p + "self_attn.v_proj.weight"] = mat(kv, h)
+        sd[p + "self_attn.o_proj.weight"] = mat(h, h)
+        sd[p + "post_attention_layernorm.weight"] = norm(h)
+        sd[p + "mlp.up_proj.weight"] = mat(inter, h)
+        sd[p + "mlp.gate_proj.weight"] = mat(inter, h)
+        sd[p + "mlp.down_proj.weight"] = mat(h, inter)
+    return sd
+
+
+EXAMPLE_PROMPTS = ["Life blooms like a flower, far away", "one two three four five",
+                   "A B C D E F G H I J K L M N O P Q R S T U V", "To be or not to be,"]
+
+
+def write_tokenizer(path: str, vocab_size: int):
+    """A word-level tokenizer (tokenizer.json + tokenizer_config.json, loadable by transformers.AutoTokenizer with no
+    network) whose vocabulary holds the words of the reference's example prompts (examples/offline.py:47-52,
+    examples/online.py:66-71) and filler words up to `vocab_size`: every id a `vocab_size`-token model can emit
+    decodes to a word."""
+    from tokenizers import Tokenizer, decoders, models, pre_tokenizers
+    words = ["<unk>", "<s>", "</s>"] + sorted(set(" ".join(EXAMPLE_PROMPTS).split()))
+    assert len(words) <= vocab_size
+    vocab = {w: i for i, w in enumerate(words)}
+    for i in range(len(vocab), vocab_size):
+        vocab[f"w{i}"] = i
+    tok = Tokenizer(models.WordLevel(vocab=vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    tok.decoder = decoders.WordPiece(prefix="##")       # joins words with single spaces
+    os.makedirs(path, exist_ok=True)
+    tok.save(os.path.join(path, "tokenizer.json"))
+    with open(os.path.join(path, "tokenizer_config.json"), "w", encoding="utf-8") as f:
+        json.dump({"tokenizer_class": "PreTrainedTokenizerFast", "unk_token": "<unk>", "bos_token": "<s>",
+                   "eos_token": "</s>", "model_max_length": 1 << 20}, f)
+    return path
+
+
 def write_model_dir(path: str, cfg: dict, state_dict: dict = None, fmt: str = "safetensors"):
     """config.json (+ weights) in `path`. state_dict=None writes the config only (use_dummy runs)."""
     os.makedirs(path, exist_ok=True)

@@ -70,8 +70,7 @@ class BlockAllocatorHost:
                 f"{self.num_free_blocks} free, {total} requested)")
         if total == 0:
             return needed, np.empty(0, dtype=np.int32)
-        lo = self._lowest_maybe_free
-        picked = np.flatnonzero(self.is_free[lo:])[:total].astype(np.int32) + lo
+        picked = self._lowest_free(total)
         self.is_free[picked] = False
         self.num_free_blocks -= total
         self._lowest_maybe_free = int(picked[-1]) + 1
@@ -81,6 +80,21 @@ class BlockAllocatorHost:
                 self.seq_blocks.setdefault(sid, []).extend(picked[off:off + n].tolist())
                 off += n
         return needed, picked
+
+    def _lowest_free(self, total: int) -> np.ndarray:
+        """The `total` lowest free block ids (the caller has checked that many exist). Scanned in windows from the first
+        index that may be free: a 288 GB pool of a small model has tens of millions of blocks, and a decode step that
+        needs one block per sequence must not pay for a scan of all of them."""
+        lo, found, have = self._lowest_maybe_free, [], 0
+        window = max(4096, 4 * total)
+        while have < total:
+            hit = np.flatnonzero(self.is_free[lo:lo + window])
+            if hit.size:
+                found.append(hit[:total - have].astype(np.int32) + lo)
+                have += found[-1].size
+            lo += window
+            window *= 2
+        return found[0] if len(found) == 1 else np.concatenate(found)
 
     def release(self, seq_ids: Iterable[int]) -> List[int]:
         """Free every block of the given sequences; returns the freed ids in batch order."""

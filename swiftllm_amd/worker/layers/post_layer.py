@@ -12,8 +12,9 @@ class LlamaPostLayer:
         self.weights = weights
         self.skinny = False     # set by LlamaModel from EngineConfig.use_skinny_gemm
         # tests set this to a list: every forward appends its pre-argmax logits (the DEVICE tensor — no
-        # host copy here, a forward may be under hipGraph capture)
+        # host copy here, a forward may be under hipGraph capture; LlamaModel appends a copy after each replay)
         self.logits_tap = None
+        self.last_logits = None     # the logits tensor of the most recent (eager or captured) forward
 
     def forward(self, input_embds: torch.Tensor, infer_state) -> torch.Tensor:
         """[num_tokens, hidden] -> next-token ids int64 [batch_size] (argmax; ties -> lowest id)."""
@@ -32,6 +33,7 @@ class LlamaPostLayer:
         """lm_head + greedy sampling on rows that already went through the final norm (a pure-decode batch whose
         last add + norm ran fused on the split-K partials of the last down projection: every row is a last token)."""
         logits = linear(last_input, self.weights.lm_head, self.skinny)   # [batch, vocab]
+        self.last_logits = logits
         if self.logits_tap is not None:
             self.logits_tap.append(logits)
         return argmax_rows(logits)

@@ -54,7 +54,7 @@ def _require_hip_device():
 
 class _DecodeGraph:
     """A captured pure-decode forward for one batch size."""
-    __slots__ = ("graph", "out_tokens", "seq_block_size", "num_seq_blocks")
+    __slots__ = ("graph", "out_tokens", "logits", "seq_block_size", "num_seq_blocks")
 
 
 class LlamaModel:
@@ -301,6 +301,8 @@ class LlamaModel:
         key = (plan.batch_size, sbs, nsb_cap)
         entry = self._decode_graphs.pop(key, None)
         plan.seq_block_size, plan.num_seq_blocks = sbs, nsb_cap
+        tap = self.post_layer.logits_tap
+        tap_len = len(tap) if tap is not None else 0
         if entry is None:
             state = self._make_infer_state(plan, dev, False)
             # one eager run on a side stream first (library handles, workspaces, allocator pools):
@@ -320,9 +322,14 @@ class LlamaModel:
             entry.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(entry.graph, pool=self._graph_pool):
                 entry.out_tokens = self._forward(dev["input_ids"], state)
+            entry.logits = self.post_layer.last_logits
             entry.seq_block_size, entry.num_seq_blocks = sbs, nsb_cap
+            if tap is not None:
+                del tap[tap_len:]               # what the warm-up run and the capture appended
         self._decode_graphs[key] = entry        # (re)inserted last = most recently used
         entry.graph.replay()
+        if tap is not None:                     # (tests) one entry per forward, as on the eager path; a copy: the
+            tap.append(entry.logits.clone())    # graph's own tensor is overwritten by the next replay
         return entry.out_tokens
 
     # ------------------------------------------------------------------------------------------------

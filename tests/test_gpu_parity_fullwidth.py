@@ -43,7 +43,7 @@ CASES = {
     "configs2_batch32": ([1024, 1, 15, 16, 17, 100, 257, 640, 33, 1000, 511, 512, 513, 64, 128, 900,
                           1024, 2, 31, 48, 300, 700, 800, 5, 1023, 256, 255, 77, 450, 999, 10, 129], 5),
 }
-VARIANTS = (("default", dict()), ("hipgraph", dict(use_hip_graph=True)),
+VARIANTS = (("default", dict()), ("eager_launches", dict(use_hip_graph=False)),
             ("row_major_weights", dict(pack_decode_weights=False)),
             ("exact_rmsnorm_rounding", dict(defer_rmsnorm=False)))
 
@@ -124,7 +124,8 @@ def test_full_width_forward_matches_oracle(tmp_path, case, dtype):
                 top2 = b[i].topk(2).values
                 ties.append(float(top2[0] - top2[1]))
             rows.append(dict(step=s, max_abs=float(d.max()), max_ulp_of_row=float((d / row_ulp).max()),
-                             mismatches=len(mism), mismatch_top2_gaps=ties))
+                             mismatches=len(mism), mismatch_top2_gaps=ties,
+                             mismatch_row_max_abs=[float(d[i].max()) for i in mism]))
         return rows
 
     report = dict(case=case, dtype=dtype, batch=batch, decode_steps=steps, model=CFG,
@@ -141,10 +142,12 @@ def test_full_width_forward_matches_oracle(tmp_path, case, dtype):
             failures.append(f"{name}: logits off by {worst_ulp:.2f} ulp of the row scale ({worst_abs:.2e} abs); "
                             f"the reference's own score rounding is {noise_ulp:.2f} ulp from the exact oracle")
         for r in rows:
-            for gap in r["mismatch_top2_gaps"]:
-                if gap > 2 * worst_abs:
+            # PER ROW: a greedy id may differ from the oracle's only where the oracle's own top-2 gap in
+            # that row is within twice THAT ROW's logit distance — not the run's worst
+            for gap, row_abs in zip(r["mismatch_top2_gaps"], r["mismatch_row_max_abs"]):
+                if gap > 2 * row_abs:
                     failures.append(f"{name}: token mismatch at step {r['step']} with oracle top-2 gap {gap:.2e} "
-                                    f"> 2 x logit distance {worst_abs:.2e}")
+                                    f"> 2 x the row's logit distance {row_abs:.2e}")
     def summarise(rows):
         return dict(max_abs=max(r["max_abs"] for r in rows), max_ulp_of_row=max(r["max_ulp_of_row"] for r in rows),
                     token_mismatches=sum(r["mismatches"] for r in rows),
@@ -155,6 +158,90 @@ def test_full_width_forward_matches_oracle(tmp_path, case, dtype):
     with open(os.path.join(out_dir, f"parity_fullwidth_{case}_{dtype}.json"), "w", encoding="utf-8") as f:
         json.dump(report, f, indent=1)
     print("\n[full-width parity]", case, dtype, json.dumps(report["summary"]))
+    assert not failures, failures
+
+
+STAGED = os.path.isfile(os.path.join(ROOT, "oracle", "_ref", "swiftllm", "worker", "model.py"))
+
+
+def test_full_width_logits_hold_the_absolute_1e3_bar_when_it_is_meaningful(tmp_path):
+    """north_star: "pre-argmax logits within 1e-3 of the reference Triton path". At |logit| 4-8 that is a quarter of an
+    fp16 ulp (spacing 3.9e-3) — not a bar any fp16 implementation, the reference's own two paths included, can be held
+    to. Here the SAME Llama-3-8B-width model (hidden 4096, 32/8 heads of 128, FFN 14336, 2 layers, batch 32 at ~1k
+    contexts, fp16) gets an lm_head drawn 16x smaller, so that every logit has |logit| <= 0.5 (asserted): the fp16
+    spacing is then <= 2.4e-4 and 1e-3 is a real bound — and it is ASSERTED, for prefill + 5 decode steps, against
+    (a) the CPU oracle with exact scores and (b) the compiled reference Triton path on this GPU (when staged)."""
+    import subprocess
+    import sys
+    from swiftllm_amd import EngineConfig, LlamaModel, LlamaModelConfig
+    lens, steps = CASES["configs2_batch32"]
+    batch = len(lens)
+    cfg = synth.make_config(**CFG)
+    sd = synth.make_state_dict(cfg, seed=31, dtype=torch.float16)
+    sd["lm_head.weight"] = (sd["lm_head.weight"].float() / 16).to(torch.float16)
+    g = torch.Generator().manual_seed(8)
+    prompts = [torch.randint(0, cfg["vocab_size"], (n,), generator=g).tolist() for n in lens]
+    seq_ids = list(range(batch))
+    num_blocks = sum(-(-(n + steps + 1) // 16) for n in lens) + 4
+    kw = _engine_kw(batch, "float16")
+    synth.write_model_dir(str(tmp_path / "model"), cfg, sd)
+
+    ref = RefLlamaModel(LlamaModelConfig(cfg), EngineConfig(model_path="", **kw), sd, torch.float16, score_dtype="fp32")
+    ref.init_kvcache_and_swap(num_blocks)
+    want_toks, want_logits = [ref.forward(prompts, seq_ids, [])], [ref.last_logits.clone()]
+    cur = list(lens)
+    script = [dict(input_ids=prompts, seq_ids=seq_ids, dec_lens=[])]
+    for s in range(steps):
+        cur = [n + 1 for n in cur]
+        want_toks.append(ref.forward([[t] for t in want_toks[-1]], seq_ids, list(cur)))
+        want_logits.append(ref.last_logits.clone())
+        script.append(dict(input_ids=[[t] for t in want_toks[-2]], seq_ids=seq_ids, dec_lens=list(cur)))
+    del ref, sd
+    top = max(float(l.abs().max()) for l in want_logits)
+    assert top <= 0.5, top                      # the premise: 1e-3 is >= 4 fp16 ulps everywhere
+
+    report = dict(model=CFG, lm_head_scale=1 / 16, batch=batch, steps=steps + 1, max_abs_logit=top)
+    tri_logits = None
+    if STAGED:      # the compiled reference on the same checkpoint, teacher-forced with the oracle's tokens
+        torch.save(dict(config=cfg, model_path=str(tmp_path / "model"), num_blocks=num_blocks, max_len=1040,
+                        steps=script), tmp_path / "job.pt")
+        env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+        env.pop("TRITON_INTERPRET", None)
+        r = subprocess.run([sys.executable, "-m", "oracle.ref_triton", "forward", str(tmp_path / "job.pt"),
+                            str(tmp_path / "ref.pt")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        tri_logits = [x["logits"] for x in torch.load(tmp_path / "ref.pt", weights_only=False)]
+        report["reference_triton_vs_oracle_max_abs"] = max(float((a - b).abs().max()) for a, b in zip(tri_logits, want_logits))
+
+    failures = []
+    for name, opts in (("default", dict()), ("eager_launches", dict(use_hip_graph=False)),
+                       ("reference_blas_calls", dict(fuse_qkv=False, use_skinny_gemm=False))):
+        model = LlamaModel(EngineConfig(model_path=str(tmp_path / "model"), **kw, **opts))
+        model.load_weights()
+        model.init_kvcache_and_swap(num_blocks)
+        model.post_layer.logits_tap = []
+        tap = model.post_layer.logits_tap
+        logits = []
+        for s, step in enumerate(script):
+            model.forward(step["input_ids"], step["seq_ids"], step["dec_lens"])
+            logits.append(tap[-1].float().cpu())
+        del model
+        torch.cuda.empty_cache()
+        vs_oracle = max(float((a - b).abs().max()) for a, b in zip(logits, want_logits))
+        entry = dict(vs_oracle_max_abs=vs_oracle)
+        if vs_oracle > 1e-3:
+            failures.append(f"{name}: {vs_oracle:.3e} from the exact-score oracle")
+        if tri_logits is not None:
+            vs_tri = max(float((a - b).abs().max()) for a, b in zip(logits, tri_logits))
+            entry["vs_reference_triton_max_abs"] = vs_tri
+            if vs_tri > 1e-3:
+                failures.append(f"{name}: {vs_tri:.3e} from the compiled reference Triton path")
+        report[name] = entry
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "parity_fullwidth_scaled_logits_float16.json"), "w", encoding="utf-8") as f:
+        json.dump(report, f, indent=1)
+    print("\n[full-width, |logit| <= 0.5: the absolute 1e-3 bar]", json.dumps(report))
     assert not failures, failures
 
 

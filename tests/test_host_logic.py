@@ -402,3 +402,30 @@ def test_tiny_batch_projection_policy():
     assert L.attn_partials_ok(1, 32, 128, weight(4096, 4096)) and not L.attn_partials_ok(5, 32, 128, weight(4096, 4096))
     assert not L.attn_partials_ok(1, 32, 128, weight(4096, 2048))                  # K != H * D
     assert not L.attn_partials_ok(1, 4, 32, weight(128, 128))                      # o_proj not split over K: nothing to fuse
+
+
+def test_windowed_lowest_free_scan_equals_the_full_scan():
+    """BlockAllocatorHost._lowest_free scans in windows (a 288 GB pool of a small model has tens of millions of blocks);
+    it must hand out exactly the ids the reference's full scan does (torch.nonzero(is_block_free)[:n],
+    block_manager.py:50) under random allocate / free traffic, holes and a nearly full pool included."""
+    import numpy as np
+    from swiftllm_amd.worker.block_manager import BlockAllocatorHost
+    rng = np.random.default_rng(5)
+    host = BlockAllocatorHost("GPU", 50_000, 64, 40_000, 16)
+    lens = {}
+    for step in range(300):
+        sid = int(rng.integers(0, 64))
+        if sid in lens and rng.random() < 0.4:
+            host.release([sid])
+            del lens[sid]
+            continue
+        grow = int(rng.choice([1, 16, 17, 500, 9000, 70_000]))
+        want = lens.get(sid, 0) + grow
+        need = -(-want // 16) - host.num_allocated(sid)
+        if need > host.num_free_blocks or -(-want // 16) > 40_000:
+            continue
+        expect = np.flatnonzero(host.is_free)[:need]
+        _, picked = host.plan_allocation([sid], [want])
+        assert np.array_equal(picked, expect), step
+        lens[sid] = want
+    assert host.num_free_blocks == int(host.is_free.sum())

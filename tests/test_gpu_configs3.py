@@ -145,8 +145,9 @@ def test_configs3_decode_forward_vs_oracle_and_replay_equals_eager(tmp_path, dty
         model = LlamaModel(EngineConfig(model_path=str(tmp_path), **kw, **opts))
         model.load_weights()
         model.init_kvcache_and_swap(num_blocks)
-        model.k_cache.copy_(k0)
-        model.v_cache.copy_(v0)
+        with torch.inference_mode():
+            model.k_cache.copy_(k0)
+            model.v_cache.copy_(v0)
         model._eager_uses_graph_buckets = bucketed
         model.post_layer.logits_tap = []
         toks, logits, c, f = [], [], list(first), toks0

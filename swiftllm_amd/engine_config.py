@@ -41,29 +41,31 @@ class EngineConfig:
     # graph launch per step instead of ~230 kernel launches (batch 32: 4.0 vs 4.35 ms/step on MI355X). The default;
     # False (CLI: --no-hip-graph) launches every kernel from Python.
     use_hip_graph: bool = True
-    # Fused rotary + decode KV store (one launch instead of two) on pure-decode batches.
-    fuse_rope_kvstore: bool = True
     # Route decode-sized projections (<= 32 tokens) to the hand-written weight-streaming MFMA GEMM
     # instead of hipBLASLt (prefill-sized calls stay on the BLAS).
     use_skinny_gemm: bool = True
-    # On the skinny-GEMM decode path, let the next kernel sum split-K partial slabs (no reduce launches).
-    fuse_splitk_consumers: bool = True
     # Keep a second copy of the projection weights in MFMA-fragment order for the decode GEMMs (+1x projection
     # weights in HBM, ~8 % faster weight streaming; the row-major copy stays for prefill).
     pack_decode_weights: bool = True
-    # Pure-decode batches on the split-K path: rotary + KV store run in the paged-attention kernel's prologue.
-    fuse_rope_into_attention: bool = True
-    # Decode batches of <= 32 sequences: apply the RMSNorm scale AFTER the projection that consumes the normalised
-    # activations (it is a per-token scalar), so the residual-add + norm split-K consumers become element-wise kernels
-    # that fill the chip instead of one workgroup per token. Moves one rounding (the un-normalised
-    # activations are rounded, the scale is applied in fp32); bfloat16 only (float16's exponent range cannot hold the
-    # un-normalised intermediate safely: it keeps the reference's rounding points) and hidden % 1024 == 0.
-    defer_rmsnorm: bool = True
-    # Decode batches of <= 4 sequences: the qkv and up/gate projections sum the previous projection's split-K slabs
-    # themselves (csrc/gemm_tiny.hip) — 5 launches per layer instead of 7. Needs defer_rmsnorm, packed weights, hidden <= 4096.
-    tiny_decode_batches: bool = True
-    # Allocate the host swap pool in pinned memory (true async DMA for swap_blocks).
-    pin_swap_memory: bool = True
+    # Overrides of the internal decode-path switches below (TUNING_DEFAULTS), e.g. tuning={"defer_rmsnorm": False}: every
+    # one of them selects between two parity-tested implementations of the same arithmetic and defaults to the faster one;
+    # they exist so that tests and A/B measurements can hold one path against the other, not as deployment knobs.
+    tuning: dict = None
+
+    # Internal switches (all on): set through `tuning`, read by the layer code as plain attributes.
+    TUNING_DEFAULTS = dict(
+        fuse_rope_kvstore=True,         # pure-decode batches: rotary + decode KV store in one launch instead of two
+        fuse_splitk_consumers=True,     # the next kernel sums a projection's split-K slabs (no reduce launches)
+        fuse_rope_into_attention=True,  # ... and rotary + KV store run in the paged-attention kernel's prologue
+        # apply the RMSNorm scale AFTER the projection that consumes the normalised activations (a per-token scalar), so the
+        # residual-add + norm consumers become element-wise kernels that fill the chip; bfloat16 only
+        # (kernels/rmsnorm.py: deferred_norm_ok), hidden % 1024 == 0, batches of <= 32 sequences
+        defer_rmsnorm=True,
+        # batches of <= 2 sequences: the qkv and up/gate projections sum the previous projection's slabs themselves
+        # (csrc/gemm_tiny.hip), 5 launches per layer instead of 7
+        tiny_decode_batches=True,
+        pin_swap_memory=True,           # host swap pool in pinned memory (falls back to pageable when the host refuses)
+    )
 
     # Tokens per KV block the HIP kernels are built for (csrc/paged_attn.hip kBlk, kvcache.hip): one 16-token block
     # of a 128-wide head is 4 KiB = one wave-wide 16 B/lane load x 4.
@@ -79,6 +81,11 @@ class EngineConfig:
                 f"{self.SUPPORTED_BLOCK_SIZE}-token KV blocks (pass --block-size {self.SUPPORTED_BLOCK_SIZE})")
         if self.dtype not in ("float16", "bfloat16"):
             raise ValueError(f"dtype must be 'float16' or 'bfloat16', got {self.dtype!r}")
+        unknown = set(self.tuning or ()) - set(self.TUNING_DEFAULTS)
+        if unknown:
+            raise ValueError(f"unknown tuning switches {sorted(unknown)}; known: {sorted(self.TUNING_DEFAULTS)}")
+        for name, default in self.TUNING_DEFAULTS.items():
+            setattr(self, name, bool((self.tuning or {}).get(name, default)))
 
     @staticmethod
     def add_cli_args(parser: argparse.ArgumentParser):

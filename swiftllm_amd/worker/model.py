@@ -20,6 +20,8 @@ so examples/offline.py and the Engine drive it unchanged. Inside, the host side 
 The compute backend is libswiftllm_hip.so only; without a HIP device this class raises.
 """
 import math
+import os
+import time
 from typing import List, Optional
 
 import numpy as np
@@ -57,6 +59,11 @@ class _DecodeGraph:
     __slots__ = ("graph", "out_tokens", "logits", "seq_block_size", "num_seq_blocks")
 
 
+class _DecodeLookahead:
+    """Everything the NEXT decode step of the same batch needs, prepared while the GPU was still busy with this one."""
+    __slots__ = ("seq_ids", "lens", "tokens", "plan", "dev")
+
+
 class LlamaModel:
     """A LLaMA model resident on one GPU, driven by the control plane (or directly, offline)."""
 
@@ -84,7 +91,13 @@ class LlamaModel:
         self._meta_done = None
         self._num_slots = 256        # CUs: one 8-wave paged-attention workgroup each
         self._decode_graphs = {}     # (batch, split width, split count) -> _DecodeGraph, in LRU order
+        self._lookahead = None       # _DecodeLookahead of the step that is expected next (graph replay only)
+        self._decode_lookahead = True    # (tests switch it off to hold the fast path to the plain one)
+        self._la_host = self._la_host_np = self._la_done = None
         self._eager_uses_graph_buckets = False   # tests: eager launches at the replay path's split geometry
+        # SWL_HOST_PROFILE=1: wall-clock split of forward() on the host (plan / blocks / upload / launch / wait for the
+        # tokens), summed over calls — tools read it with host_profile()
+        self._host_prof = {} if os.environ.get("SWL_HOST_PROFILE") else None
         self._graph_pool = None
         self._scratch = None
 
@@ -184,6 +197,7 @@ class LlamaModel:
                                               ecfg.max_seqs_in_block_table, ecfg.max_blocks_per_seq,
                                               ecfg.block_size, self.device)
         self._decode_graphs.clear()
+        self._lookahead = None
 
     def _init_to_get_rotary(self):
         """cos/sin tables [positions, head_dim/2] in the model dtype. Formulas (including the
@@ -332,6 +346,50 @@ class LlamaModel:
             tap.append(entry.logits.clone())    # graph's own tensor is overwritten by the next replay
         return entry.out_tokens
 
+    # ---- decode look-ahead: the host side of step k+1 runs while the GPU executes step k ---------------------------------
+    def _prepare_next_decode(self, plan: BatchPlan, seq_ids_list: List[int], tokens_dev: torch.Tensor):
+        """Called right after the graph of a pure-decode step was launched, before the host blocks on its tokens. A
+        generation loop calls forward again with the same sequences, every length + 1 and the tokens just sampled: plan
+        that step now (numpy) and enqueue — behind the running graph, on the same stream — the H2D copy of its metadata and
+        a device copy of the sampled tokens into its input-id slots. If the next call is that step (forward checks), it
+        only takes its KV blocks and launches: ~40 us of host work per step the GPU no longer waits for
+        (tools/host_overhead.py: plan 18 + upload 24 us at batch 32). If it is not, nothing is lost: the ordinary path
+        re-plans and re-uploads. (Blocks are NOT taken early: a scheduler that counts the pool down to its last block must
+        find the allocator exactly where its own books say it is.)"""
+        next_lens = [n + 1 for n in plan.seq_lengths_list]
+        if max(next_lens) > self._cos_cached.shape[0]:
+            return None
+        nxt = plan_batch([(0,)] * plan.batch_size, seq_ids_list, next_lens, self.model_config.num_kv_heads,
+                         self._num_slots)
+        layout, total = nxt.packed_layout()
+        if self._la_host is None or self._la_host.numel() < total:
+            self._la_host = torch.empty(max(total, self._meta_host.numel()), dtype=torch.int32, pin_memory=True)
+            self._la_host_np = self._la_host.numpy()
+            self._la_done = torch.cuda.Event()
+        else:
+            self._la_done.synchronize()     # (the previous look-ahead copy out of this pinned buffer: long done)
+        nxt.pack_into(self._la_host_np)
+        self._meta_dev[:total].copy_(self._la_host[:total], non_blocking=True)
+        self._la_done.record()
+        dev = {name: self._meta_dev[off:off + n] for name, off, n in layout}
+        dev["input_ids"].copy_(tokens_dev)      # int64 -> int32 on the device: the host has not seen them yet
+        la = _DecodeLookahead()
+        la.seq_ids, la.lens, la.plan, la.dev, la.tokens = list(seq_ids_list), next_lens, nxt, dev, None
+        return la
+
+    def _take_lookahead(self, input_ids_list, seq_ids_list, decoding_seq_lens_list, ignore_kvcache):
+        """The prepared step, if this call is it (any other call drops the preparation)."""
+        la, self._lookahead = self._lookahead, None
+        if (la is None or la.tokens is None or ignore_kvcache or not self._decode_lookahead
+                or not getattr(self.engine_config, "use_hip_graph", False)
+                or len(input_ids_list) != len(la.lens) or list(decoding_seq_lens_list) != la.lens
+                or list(seq_ids_list) != la.seq_ids):
+            return None
+        for ids, tok in zip(input_ids_list, la.tokens):
+            if len(ids) != 1 or ids[0] != tok:
+                return None
+        return la
+
     # ------------------------------------------------------------------------------------------------
     @torch.inference_mode()
     def forward(self, input_ids_list: List[List[int]], seq_ids_list: List[int],
@@ -342,6 +400,23 @@ class LlamaModel:
         if len(input_ids_list) == 0:
             return []   # the reference's idle engine calls forward([], [], []) in a loop
         _require_hip_device()
+        prof = self._host_prof
+        t0 = time.perf_counter() if prof is not None else 0.0
+        la = self._take_lookahead(input_ids_list, seq_ids_list, decoding_seq_lens_list, ignore_kvcache)
+        if la is not None:      # the step that was prepared while the previous one ran: blocks, then the launch
+            self.gpu_block_manager.allocate_blocks_for_seqs(la.seq_ids, la.lens)
+            tokens = self._forward_decode_graph(la.plan, la.dev)
+            nxt = self._prepare_next_decode(la.plan, la.seq_ids, tokens)
+            t4 = time.perf_counter() if prof is not None else 0.0
+            out = tokens.tolist()
+            if nxt is not None:
+                nxt.tokens = out
+            self._lookahead = nxt
+            if prof is not None:
+                for name, dt in (("launch", t4 - t0), ("wait_tokens", time.perf_counter() - t4), ("calls", 1.0),
+                                 ("lookahead_hits", 1.0)):
+                    prof[name] = prof.get(name, 0.0) + dt
+            return out
         plan = plan_batch(input_ids_list, seq_ids_list, decoding_seq_lens_list,
                           self.model_config.num_kv_heads, self._num_slots)
         longest = max(plan.seq_lengths_list)
@@ -350,17 +425,47 @@ class LlamaModel:
             raise RuntimeError(
                 f"sequence length {longest} exceeds the rotary table ({self._cos_cached.shape[0]} positions = "
                 "max_position_embeddings * rope_scaling + 128); use a checkpoint with rope scaling")
+        t1 = time.perf_counter() if prof is not None else 0.0
         if not ignore_kvcache:
             self.gpu_block_manager.allocate_blocks_for_seqs(seq_ids_list, plan.seq_lengths_list)
+        t2 = time.perf_counter() if prof is not None else 0.0
         dev = self._upload_plan(plan)
+        t3 = time.perf_counter() if prof is not None else 0.0
         pure_decode = plan.num_prefill_seqs == 0
+        nxt = None
         if (pure_decode and not ignore_kvcache and getattr(self.engine_config, "use_hip_graph", False)):
             tokens = self._forward_decode_graph(plan, dev)
+            if self._decode_lookahead:
+                nxt = self._prepare_next_decode(plan, list(seq_ids_list), tokens)
         else:
             if pure_decode and not ignore_kvcache and self._eager_uses_graph_buckets:
                 plan.seq_block_size, plan.num_seq_blocks = self._graph_bucket(plan)
             tokens = self._forward(dev["input_ids"], self._make_infer_state(plan, dev, ignore_kvcache))
-        return tokens.tolist()
+        if prof is None:
+            out = tokens.tolist()
+            if nxt is not None:
+                nxt.tokens = out
+            self._lookahead = nxt
+            return out
+        t4 = time.perf_counter()
+        out = tokens.tolist()
+        t5 = time.perf_counter()
+        if nxt is not None:
+            nxt.tokens = out
+        self._lookahead = nxt
+        for name, dt in (("plan", t1 - t0), ("blocks", t2 - t1), ("upload", t3 - t2), ("launch", t4 - t3),
+                         ("wait_tokens", t5 - t4), ("calls", 1.0)):
+            prof[name] = prof.get(name, 0.0) + dt
+        return out
+
+    def host_profile(self, reset: bool = True) -> dict:
+        """Mean host seconds per forward() call by section (SWL_HOST_PROFILE=1), {} when profiling is off."""
+        prof = self._host_prof or {}
+        n = prof.get("calls", 0.0)
+        out = {k: v / n for k, v in prof.items() if k != "calls"} if n else {}
+        if reset and self._host_prof is not None:
+            self._host_prof.clear()
+        return out
 
     # ---- swapping ----------------------------------------------------------------------------------------
     def _swap(self, seq_ids_list: List[int], is_swap_in: bool):
@@ -368,6 +473,7 @@ class LlamaModel:
         Reference: model.py:361-379. Block ids come from the host mirrors — no device read-back."""
         if len(seq_ids_list) == 0:
             return
+        self._lookahead = None
         src_mgr = self.cpu_block_manager if is_swap_in else self.gpu_block_manager
         dst_mgr = self.gpu_block_manager if is_swap_in else self.cpu_block_manager
         counts = src_mgr.get_num_allocated_blocks_host(seq_ids_list)
@@ -392,5 +498,6 @@ class LlamaModel:
         """Release everything the sequences hold, on both pools. Reference: model.py:402-408."""
         if len(seq_ids_list) == 0:
             return
+        self._lookahead = None
         self.gpu_block_manager.free_blocks_for_seqs(seq_ids_list)
         self.cpu_block_manager.free_blocks_for_seqs(seq_ids_list)

@@ -2,6 +2,8 @@
 against (a) the golden run of the reference's own LlamaModel.forward and (b) the oracle model, on
 random-init checkpoints. Bar (BASELINE.json north_star): greedy token ids identical, pre-argmax
 logits within 1e-3 (fp16; bf16 is held to its own rounding: 8 mantissa bits)."""
+import os
+
 import pytest
 import torch
 
@@ -32,8 +34,8 @@ def _make_model(tmp_path, cfg, sd, num_blocks=24, **kw):
 
 @pytest.mark.parametrize("opts", [dict(), dict(fuse_qkv=False, use_skinny_gemm=False),
                                   dict(fuse_qkv=False), dict(use_skinny_gemm=False),
-                                  dict(fuse_rope_kvstore=False), dict(use_hip_graph=False),
-                                  dict(fuse_rope_into_attention=False), dict(pack_decode_weights=False)],
+                                  dict(tuning=dict(fuse_rope_kvstore=False)), dict(use_hip_graph=False),
+                                  dict(tuning=dict(fuse_rope_into_attention=False)), dict(pack_decode_weights=False)],
                          ids=["default", "reference_blas_calls", "unfused_qkv", "blas_gemm", "unfused_rope",
                               "eager_launches", "rope_kernel", "row_major_weights"])
 def test_forward_matches_reference_golden(tmp_path, golden, opts):
@@ -337,7 +339,7 @@ def test_full_width_layers_fast_path_equals_reference_op_sequence(tmp_path, dtyp
 @pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
 @pytest.mark.parametrize("batch", [1, 2])
 def test_tiny_batch_decode_path_equals_the_consumer_path(tmp_path, dtype, batch):
-    """EngineConfig.tiny_decode_batches at Llama-3-8B layer geometry (2 layers): the <= 4-sequence path (projections that
+    """The tiny_decode_batches switch (EngineConfig.tuning) at Llama-3-8B layer geometry (2 layers): the <= 4-sequence path (projections that
     sum the previous projection's slabs themselves, residual ping-pong) against the same engine with it switched off —
     same greedy tokens over 8 decode steps with and without hipGraph replay, logits within the storage dtype's rounding
     (the only arithmetic difference is the fp32 summation order of the sums of squares)."""
@@ -371,7 +373,7 @@ def test_tiny_batch_decode_path_equals_the_consumer_path(tmp_path, dtype, batch)
         torch.cuda.empty_cache()
         return toks, logits
 
-    ref_toks, ref_logits = run(dict(tiny_decode_batches=False))
+    ref_toks, ref_logits = run(dict(tuning=dict(tiny_decode_batches=False)))
     eps = 2.0 ** -10 if dtype == "float16" else 2.0 ** -7
     for opts in (dict(), dict(use_hip_graph=False)):
         toks, logits = run(opts, forced=ref_toks)
@@ -432,3 +434,64 @@ def test_decode_fast_path_survives_realistic_norm_weights_and_residual_outliers(
         lens = [n + 1 for n in lens]
         got = model.forward([[t] for t in want], seq_ids, list(lens))       # teacher-forced with the oracle's tokens
         want = ref.forward([[t] for t in want], seq_ids, list(lens))
+
+
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_decode_lookahead_changes_nothing_but_the_host_path(tmp_path, dtype):
+    """LlamaModel prepares the next decode step's metadata while the GPU runs the current one (model.py:
+    _prepare_next_decode) and skips plan + upload when the next call is exactly that step. Same graphs, same kernels, same
+    data: tokens and logits must be BIT-equal to the model with the look-ahead off, through block-boundary crossings,
+    graph-bucket changes, a call that breaks the prediction (other input tokens), a freed-and-reused sequence slot, a
+    prefill in between, and a shrinking batch; and the fast path must actually have been taken."""
+    cfg = synth.make_config(**synth.SMALL64)
+    tdtype = torch.float16 if dtype == "float16" else torch.bfloat16
+    sd = synth.make_state_dict(cfg, seed=13, dtype=tdtype)
+    g = torch.Generator().manual_seed(9)
+    prompts = [torch.randint(0, cfg["vocab_size"], (n,), generator=g).tolist() for n in (14, 31, 1, 60)]
+    extra = torch.randint(0, cfg["vocab_size"], (9,), generator=g).tolist()
+    os.environ["SWL_HOST_PROFILE"] = "1"
+    try:
+        def run(lookahead):
+            model = _make_model(tmp_path / ("on" if lookahead else "off"), cfg, sd, 64, max_blocks_per_seq=32,
+                                max_tokens_in_batch=512, dtype=dtype)
+            model._decode_lookahead = lookahead
+            tap = model.post_layer.logits_tap
+            trace = []
+
+            def fwd(ids, seqs, lens):
+                toks = model.forward(ids, seqs, lens)
+                trace.append((toks, tap[-1].float().cpu().clone()))
+                return toks
+            seqs = [0, 1, 2, 3]
+            toks = fwd(prompts, seqs, [])
+            lens = [len(p) for p in prompts]
+            for step in range(40):          # crosses 16-token block boundaries of every sequence
+                lens = [n + 1 for n in lens]
+                feed = [[t] for t in toks]
+                if step == 7:
+                    feed[1] = [(toks[1] + 1) % cfg["vocab_size"]]      # not what was sampled: the prediction must be dropped
+                toks = fwd(feed, seqs, list(lens))
+            model.free_seqs_resources([2])                                # slot 2 leaves, a new prompt takes it
+            toks2 = fwd([extra], [2], [])
+            toks[2], lens[2] = toks2[0], len(extra)
+            for step in range(6):
+                lens = [n + 1 for n in lens]
+                toks = fwd([[t] for t in toks], seqs, list(lens))
+            model.free_seqs_resources([0])                                # the batch shrinks
+            seqs, toks, lens = seqs[1:], toks[1:], lens[1:]
+            for step in range(5):
+                lens = [n + 1 for n in lens]
+                toks = fwd([[t] for t in toks], seqs, list(lens))
+            hits = (model._host_prof or {}).get("lookahead_hits", 0.0)
+            del model
+            torch.cuda.empty_cache()
+            return trace, hits
+        base, hits_off = run(False)
+        fast, hits_on = run(True)
+    finally:
+        os.environ.pop("SWL_HOST_PROFILE", None)
+    assert hits_off == 0 and hits_on >= 40, (hits_off, hits_on)
+    assert len(base) == len(fast)
+    for i, ((ta, la), (tb, lb)) in enumerate(zip(base, fast)):
+        assert ta == tb, i
+        assert torch.equal(la, lb), i

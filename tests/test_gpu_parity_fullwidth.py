@@ -45,7 +45,7 @@ CASES = {
 }
 VARIANTS = (("default", dict()), ("eager_launches", dict(use_hip_graph=False)),
             ("row_major_weights", dict(pack_decode_weights=False)),
-            ("exact_rmsnorm_rounding", dict(defer_rmsnorm=False)))
+            ("exact_rmsnorm_rounding", dict(tuning=dict(defer_rmsnorm=False))))
 
 
 def _ulp(x: torch.Tensor, dtype) -> torch.Tensor:

@@ -429,3 +429,18 @@ def test_windowed_lowest_free_scan_equals_the_full_scan():
         assert np.array_equal(picked, expect), step
         lens[sid] = want
     assert host.num_free_blocks == int(host.is_free.sum())
+
+
+def test_engine_config_tuning_switches():
+    """The internal decode-path switches are not constructor arguments: they default on, `tuning` overrides them, and a
+    typo is an error instead of a silently ignored key."""
+    kw = dict(model_path="/x", use_dummy=True, block_size=16, gpu_mem_utilization=0.9, num_cpu_blocks=0,
+              max_seqs_in_block_table=8, max_blocks_per_seq=8, max_batch_size=2, max_tokens_in_batch=64)
+    ec = EngineConfig(**kw)
+    assert all(getattr(ec, k) is True for k in EngineConfig.TUNING_DEFAULTS)
+    ec = EngineConfig(**kw, tuning=dict(defer_rmsnorm=False))
+    assert ec.defer_rmsnorm is False and ec.tiny_decode_batches is True
+    with pytest.raises(ValueError, match="unknown tuning"):
+        EngineConfig(**kw, tuning=dict(defer_rmsnrom=False))
+    with pytest.raises(TypeError):
+        EngineConfig(**kw, defer_rmsnorm=False)     # not a constructor argument

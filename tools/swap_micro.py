@@ -21,7 +21,7 @@ for pinned in (True, False):
         _json.dump(cfg, f)
     ec = EngineConfig(model_path=path, use_dummy=True, block_size=16, gpu_mem_utilization=0.9, num_cpu_blocks=blocks,
                       max_seqs_in_block_table=64, max_blocks_per_seq=a.len // 16 + 8, max_batch_size=a.seqs,
-                      max_tokens_in_batch=4096, dtype="bfloat16", pin_swap_memory=pinned)
+                      max_tokens_in_batch=4096, dtype="bfloat16", tuning=dict(pin_swap_memory=pinned))
     model = LlamaModel(ec)
     model.init_kvcache_and_swap(blocks)      # no weights needed: only the pools and the block managers
     ids = list(range(a.seqs))

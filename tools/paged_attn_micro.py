@@ -87,8 +87,11 @@ def main():
     e = dtype.itemsize
     kv = sum(lens) * 2 * KVH * D * e
     part = B * H * nsb * (D + 1) * 4 * 2 if nsb > 1 else 0
-    alg = kv + 2 * B * H * D * e + part
-    print(json.dumps(dict(shape=a.shape, qkv_slabs=a.qkv, lib=os.environ.get("SWIFTLLM_HIP_LIB", "default"), dtype=a.dtype, H=H, KVH=KVH, D=D, batch=B, len=n, seq_block_size=sbs,
+    # as bench.py prices it: KV read once per kv head + q (or the fp32 qkv slabs the prologue sums) + o + partials
+    q_bytes = a.qkv * B * (H + 2 * KVH) * D * 4 if a.qkv else B * H * D * e
+    alg = kv + q_bytes + B * H * D * e + part
+    kernel = ("paged_attn_phase1_kernel<%s, D=%d, G=%d%s>" % (a.dtype, D, H // KVH, ", QKV: rotary + KV store in the prologue" if a.qkv else ""))
+    print(json.dumps(dict(kernel=kernel, algorithmic_bytes=alg, shape=a.shape, qkv_slabs=a.qkv, lib=os.environ.get("SWIFTLLM_HIP_LIB", "default"), dtype=a.dtype, H=H, KVH=KVH, D=D, batch=B, len=n, seq_block_size=sbs,
                           num_seq_blocks=nsb, workgroups=B * KVH * nsb, us_per_op=round(us, 2),
                           alg_bytes=alg, kv_bytes=kv, GBps=round(alg / us / 1e3, 1),
                           frac_of_8TBps=round(alg / us / 1e3 / 8000, 4), iters=a.iters)))

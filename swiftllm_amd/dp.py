@@ -72,6 +72,11 @@ def spawn_local_ranks(argv: Sequence[str], world_size: int, timeout_s: float = N
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     restricted = any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+    if visible_devices is None and os.environ.get("SWIFTLLM_SPAWN_DEVICES"):
+        # e.g. "0,0": smoke-test the N-rank launch path on a box with fewer GPUs (ranks share a device)
+        visible_devices = [d.strip() for d in os.environ["SWIFTLLM_SPAWN_DEVICES"].split(",")]
+        if len(visible_devices) != world_size:
+            raise ValueError(f"SWIFTLLM_SPAWN_DEVICES names {len(visible_devices)} devices for {world_size} ranks")
     procs = []
     for r in range(world_size):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world_size),

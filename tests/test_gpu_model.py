@@ -495,3 +495,54 @@ def test_decode_lookahead_changes_nothing_but_the_host_path(tmp_path, dtype):
     for i, ((ta, la), (tb, lb)) in enumerate(zip(base, fast)):
         assert ta == tb, i
         assert torch.equal(la, lb), i
+
+
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_llama32_1b_geometry_matches_oracle(tmp_path, dtype):
+    """The other model family the reference serves (weight.py:157-163, model.py:183-214): Llama-3.2-1B geometry — hidden
+    2048, 32 query / 8 kv heads of 64, FFN 8192, dict-style rope_scaling (the reference's home-grown frequency split) and
+    the tied lm_head it implies — 2 layers, an 8k vocabulary so the CPU side stays small. Different tile counts and
+    K-splits in every decode projection than the 8B shapes the other tests run (N = 2048 / 3072 / 16384), head_dim 64
+    attention kernels, ragged batch of 9: greedy ids of the oracle (per-row near-tie rule), logits within a few storage-
+    dtype ulps of the row scale, prefill + 12 decode steps, graph replay (default) and eager launches."""
+    from swiftllm_amd import LlamaModelConfig
+    cfg = synth.make_config(num_hidden_layers=2, hidden_size=2048, num_attention_heads=32, num_key_value_heads=8,
+                            intermediate_size=8192, vocab_size=8192, max_position_embeddings=2048, rope_theta=500000.0,
+                            rope_scaling=dict(factor=32.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                                              original_max_position_embeddings=64, rope_type="llama3"),
+                            tie_word_embeddings=True)
+    tdtype = torch.float16 if dtype == "float16" else torch.bfloat16
+    sd = synth.make_state_dict(cfg, seed=77, dtype=tdtype)
+    g = torch.Generator().manual_seed(12)
+    lens = [1, 15, 16, 17, 100, 257, 640, 33, 500]
+    prompts = [torch.randint(0, cfg["vocab_size"], (n,), generator=g).tolist() for n in lens]
+    seq_ids = list(range(len(lens)))
+    ecfg = dict(max_blocks_per_seq=48, max_tokens_in_batch=2048, max_batch_size=16, max_seqs_in_block_table=16, dtype=dtype)
+    ref = RefLlamaModel(LlamaModelConfig(cfg), _engine_config("", **ecfg), sd, tdtype, tied_lm_head=True)
+    ref.init_kvcache_and_swap(16 * 48)
+    want, want_logits = [ref.forward(prompts, seq_ids, [])], [ref.last_logits.clone()]
+    cur = list(lens)
+    for _ in range(12):
+        cur = [n + 1 for n in cur]
+        want.append(ref.forward([[t] for t in want[-1]], seq_ids, list(cur)))
+        want_logits.append(ref.last_logits.clone())
+    eps = 2.0 ** -10 if dtype == "float16" else 2.0 ** -7
+    for opts in (dict(), dict(use_hip_graph=False)):
+        model = _make_model(tmp_path / ("graph" if not opts else "eager"), cfg, sd, 16 * 48, **ecfg, **opts)
+        assert model.weight.lm_head.data_ptr() == model.weight.wte.data_ptr() or torch.equal(model.weight.lm_head, model.weight.wte)
+        cur = list(lens)
+        for s in range(13):
+            ids = prompts if s == 0 else [[t] for t in want[s - 1]]      # teacher-forced with the oracle's tokens
+            if s:
+                cur = [n + 1 for n in cur]
+            got = model.forward(ids, seq_ids, [] if s == 0 else list(cur))
+            a, b = model.post_layer.logits_tap[-1].float().cpu(), want_logits[s]
+            d = (a - b).abs()
+            scale = b.abs().amax(dim=1, keepdim=True).clamp(min=1.0)
+            assert (d <= 4 * eps * scale).all(), (opts, s, float((d / scale).max()))
+            for i, (x, y) in enumerate(zip(got, want[s])):
+                if x != y:
+                    top2 = b[i].topk(2).values
+                    assert float(top2[0] - top2[1]) <= 2 * float(d[i].max()), (opts, s, i)
+        del model
+        torch.cuda.empty_cache()

@@ -23,6 +23,7 @@ def parse():
     ap.add_argument("--max-tokens", type=int, default=8192)
     ap.add_argument("--rate", type=float, default=0.0, help="Poisson arrival rate (req/s); 0 = all at once")
     ap.add_argument("--modes", default="plain,piggyback")
+    ap.add_argument("--kv-blocks", type=int, default=0, help="KV pool size in blocks (0 = profile_num_blocks at 0.97)")
     return ap.parse_args()
 
 
@@ -68,16 +69,22 @@ async def run(model, a, piggyback):
 def main():
     a = parse()
     cfg = bench.model_config_dict(a.model)
+    # the KV pool is what the product's own sizing gives (profile_num_blocks at gpu_mem_utilization 0.97: ~125 k blocks for
+    # Llama-3-8B on a 288 GB MI355X) unless --kv-blocks says otherwise; no filler sequences: the engine hands out sequence ids
     ns = argparse.Namespace(batch=2 * a.max_batch, prompt_len=a.prompt_len, steps=a.gen_len, warmup=0, dtype=a.dtype,
-                            fuse_qkv=True, no_hip_graph=False, skinny_gemm=True, splitk_fusion=True)
+                            fuse_qkv=True, no_hip_graph=False, skinny_gemm=True, splitk_fusion=True,
+                            kv_blocks=a.kv_blocks, kv_placement="bottom")
     blocks_per_seq = (a.prompt_len + a.gen_len + 16) // 16
-    model = bench.build_model(ns, cfg, int(a.max_batch * blocks_per_seq * 1.1) + 8)
+    model = bench.build_model(ns, cfg, int(a.max_batch * blocks_per_seq * 1.1) + 8, 2 * a.max_batch,
+                              a.prompt_len + a.gen_len + 16, True)
     # scheduler limits (the block table was built for 2 x max_batch ids: running + swapped-out requests)
     model.engine_config.max_tokens_in_batch = a.max_tokens
     model.engine_config.max_batch_size = a.max_batch
     for mode in a.modes.split(","):
         res = asyncio.run(run(model, a, mode == "piggyback"))
         res["model"] = a.model
+        res["kv_pool_blocks"] = int(model.num_blocks)
+        res["kv_pool_gb"] = round(2 * model.k_cache.numel() * model.k_cache.element_size() / 1e9, 1)
         print(json.dumps(res), flush=True)
 
 

@@ -55,19 +55,20 @@ def _ulp(x: torch.Tensor, dtype) -> torch.Tensor:
 
 @pytest.fixture(scope="module")
 def checkpoints(tmp_path_factory):
-    """One 32-layer Llama-3-8B checkpoint per dtype, written once (16 GB each), removed at module teardown."""
+    """ONE 32-layer Llama-3-8B checkpoint (float16 values, 16 GB), written once and removed at module teardown. The bfloat16
+    case loads the same file: both sides round the float16 weights to bfloat16 on load (the reference: weight.py:50
+    `.to(item.dtype)`; ours: the per-tensor loader path), to the same bits."""
     made = {}
 
     def get(dtype):
-        if dtype not in made:
-            tdtype = torch.float16 if dtype == "float16" else torch.bfloat16
+        if "ckpt" not in made:
             cfg = synth.make_config(**synth.LLAMA3_8B)
-            path = str(tmp_path_factory.mktemp(f"llama3_8b_{dtype}"))
-            sd = synth.make_state_dict_on_gpu(cfg, seed=2024, dtype=tdtype)
+            path = str(tmp_path_factory.mktemp("llama3_8b"))
+            sd = synth.make_state_dict_on_gpu(cfg, seed=2024, dtype=torch.float16)
             synth.write_model_dir(path, cfg, sd)
             del sd
-            made[dtype] = (cfg, path)
-        return made[dtype]
+            made["ckpt"] = (cfg, path)
+        return made["ckpt"]
     yield get
     for _, path in made.values():
         shutil.rmtree(path, ignore_errors=True)

@@ -164,7 +164,8 @@ def test_full_width_forward_matches_oracle(tmp_path, case, dtype):
 STAGED = os.path.isfile(os.path.join(ROOT, "oracle", "_ref", "swiftllm", "worker", "model.py"))
 
 
-@pytest.mark.parametrize("shrink", [16, 32], ids=["logits_below_0.5", "logits_below_0.25"])
+@pytest.mark.parametrize("shrink", [32], ids=["logits_below_0.25"])     # (16: measured in r03, see the docstring — dividing
+# an fp16 lm_head by 2 is exact, so every distance at 32 is exactly half of its value at 16: one run says both)
 def test_full_width_logits_hold_the_absolute_1e3_bar_when_it_is_meaningful(tmp_path, shrink):
     """north_star: "pre-argmax logits within 1e-3 of the reference Triton path". At |logit| 4-8 that is a quarter of an
     fp16 ulp (spacing 3.9e-3) — not a bar any fp16 implementation, the reference's own two paths included, can be held
@@ -226,8 +227,7 @@ def test_full_width_logits_hold_the_absolute_1e3_bar_when_it_is_meaningful(tmp_p
         assert report["reference_triton_vs_oracle_max_abs"] <= 1e-3, report     # (so the bar below IS 1e-3 at this scale)
 
     failures = []
-    for name, opts in (("default", dict()), ("eager_launches", dict(use_hip_graph=False)),
-                       ("reference_blas_calls", dict(fuse_qkv=False, use_skinny_gemm=False))):
+    for name, opts in (("default", dict()), ("reference_blas_calls", dict(fuse_qkv=False, use_skinny_gemm=False))):
         model = LlamaModel(EngineConfig(model_path=str(tmp_path / "model"), **kw, **opts))
         model.load_weights()
         model.init_kvcache_and_swap(num_blocks)

@@ -6,7 +6,7 @@ the compiled reference (its own Triton kernels on this MI355X, oracle/ref_triton
 float16 -> bfloat16 twin of the reference, oracle/make_ref.py).
 
 For configs[1] (batch 1) the CPU oracle with EXACT scores (oracle/ref_model.py, fp32 accumulation everywhere, the
-reference's rounding points) additionally runs the prompt + 8 teacher-forced decode steps at full depth and arbitrates:
+reference's rounding points) additionally runs the prompt + 4 teacher-forced decode steps at full depth and arbitrates:
 both implementations' distance to it is reported, and ours must not be the larger one. (Two 16-bit implementations of a
 32-layer random-init network differ by far more than at 2 layers — every layer amplifies the 1-ulp differences of the
 one before — so "how far apart" only means something next to "how far from exact".)
@@ -206,7 +206,7 @@ def test_llama3_8b_full_depth_128_free_running_steps_vs_compiled_reference(tmp_p
         from safetensors.torch import load_file
         from oracle.ref_model import RefLlamaModel
         from swiftllm_amd import EngineConfig, LlamaModelConfig
-        n_dec = 8
+        n_dec = 4
         sd = load_file(os.path.join(path, "model.safetensors"))
         oracle = RefLlamaModel(LlamaModelConfig(cfg), EngineConfig(
             model_path="", use_dummy=False, block_size=16, gpu_mem_utilization=0.9, num_cpu_blocks=0,

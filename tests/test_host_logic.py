@@ -444,3 +444,39 @@ def test_engine_config_tuning_switches():
         EngineConfig(**kw, tuning=dict(defer_rmsnrom=False))
     with pytest.raises(TypeError):
         EngineConfig(**kw, defer_rmsnorm=False)     # not a constructor argument
+
+
+def test_decode_lookahead_is_taken_only_by_the_exact_continuation():
+    """LlamaModel._take_lookahead (host logic only): the step prepared behind the running graph is used by the call that
+    continues the same sequences with every length + 1 and exactly the tokens returned — and dropped by anything else
+    (other tokens, other lengths, other sequences, a profile run, hipGraph off, look-ahead off, tokens not yet known)."""
+    import types
+    from swiftllm_amd.worker.model import LlamaModel, _DecodeLookahead
+
+    def fresh(tokens=(7, 8, 9)):
+        m = LlamaModel.__new__(LlamaModel)
+        m.engine_config = types.SimpleNamespace(use_hip_graph=True)
+        m._decode_lookahead = True
+        la = _DecodeLookahead()
+        la.seq_ids, la.lens, la.tokens, la.plan, la.dev = [4, 0, 2], [11, 21, 31], list(tokens) if tokens else None, "plan", "dev"
+        m._lookahead = la
+        return m, la
+    ids = [[7], [8], [9]]
+    m, la = fresh()
+    assert m._take_lookahead(ids, [4, 0, 2], [11, 21, 31], False) is la and m._lookahead is None
+    for args in (([[7], [8], [1]], [4, 0, 2], [11, 21, 31], False),        # another token
+                 (ids, [4, 0, 2], [11, 21, 32], False),                    # another length
+                 (ids, [4, 2, 0], [11, 21, 31], False),                    # other sequences / order
+                 (ids[:2], [4, 0], [11, 21], False),                       # a smaller batch
+                 ([[7], [8], [9, 9]], [4, 0, 2], [11, 21, 31], False),     # not one token each
+                 (ids, [4, 0, 2], [11, 21, 31], True)):                    # a profile run (ignore_kvcache)
+        m, _ = fresh()
+        assert m._take_lookahead(*args) is None and m._lookahead is None, args
+    m, _ = fresh()
+    m.engine_config.use_hip_graph = False
+    assert m._take_lookahead(ids, [4, 0, 2], [11, 21, 31], False) is None
+    m, _ = fresh()
+    m._decode_lookahead = False
+    assert m._take_lookahead(ids, [4, 0, 2], [11, 21, 31], False) is None
+    m, _ = fresh(tokens=None)
+    assert m._take_lookahead(ids, [4, 0, 2], [11, 21, 31], False) is None

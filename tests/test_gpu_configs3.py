@@ -72,15 +72,12 @@ def test_configs3_paged_attention_vs_oracle_and_compiled_reference(tmp_path, dty
     ops.paged_attention(q, kc, vc, bt, mc, ec, _state(seq_ids, 2048, -(-max(LENS) // 2048), "cpu"), 0, want)
     tri = None
     if STAGED and dtype == torch.float16:
-        # the reference's own kernel at the reference's own split (model.py:305-324 gives 2048 for this batch). Only the
-        # blocks the four sequences own travel to the reference process, with their ids compacted (1 GB of pool otherwise).
-        used = sorted({int(b) for sid, n in zip(seq_ids, LENS) for b in bt[sid, :-(-n // 16)].tolist()})
-        remap = torch.zeros(kc.shape[0], dtype=torch.int32)
-        remap[torch.tensor(used)] = torch.arange(len(used), dtype=torch.int32)
-        bt_small = remap[bt.long()]
+        # the reference's own kernel. (Its own heuristic gives a 2048-token split for this batch, model.py:305-324; the
+        # kernel unrolls seq_block_size / 16 block iterations at compile time and the 128-fold body takes Triton ~100 s to
+        # build on a fresh box — 512 tokens compile in a quarter of that and the result is split-invariant up to fp32
+        # reassociation, which the four geometries of OUR kernel below demonstrate on the same data.)
         torch.save({"paged": dict(op="paged_attention", H=H, KVH=KVH, D=D, L=1, layer=0, lens=LENS, seq_ids=seq_ids,
-                                  seq_block_size=2048, q=q, k_cache=kc[used].clone(), v_cache=vc[used].clone(),
-                                  block_table=bt_small)}, tmp_path / "in.pt")
+                                  seq_block_size=512, q=q, k_cache=kc, v_cache=vc, block_table=bt)}, tmp_path / "in.pt")
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
         env.pop("TRITON_INTERPRET", None)
         r = subprocess.run([sys.executable, "-m", "oracle.ref_triton", "ops", str(tmp_path / "in.pt"),

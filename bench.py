@@ -43,6 +43,7 @@ Extra objects on the JSON line:
                   of its own) on the host cores, on a bounded sample.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -504,11 +505,21 @@ def side_run_fresh_process(args, label):
 
 
 def main():
+    # stdout carries exactly ONE line — the JSON result of rank 0; everything the libraries print on the way
+    # ([Model.profile] ..., engine banners) goes to stderr
+    with contextlib.redirect_stdout(sys.stderr):
+        result = _run()
+    if result is not None:
+        print(json.dumps(result), flush=True)
+
+
+def _run():
     args = parse_args()
     from swiftllm_amd import dp
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: start the N ranks ourselves, one process per GPU; rank 0 prints the JSON line
-        raise SystemExit(dp.spawn_local_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+        with contextlib.redirect_stdout(sys.__stdout__):    # rank 0's line passes straight through
+            raise SystemExit(dp.spawn_local_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     rank, local_rank, world = dp.env_rank_world()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -560,7 +571,7 @@ def main():
     graphs = len(getattr(model, "_decode_graphs", {}))
 
     if rank != 0:
-        return
+        return None
     ms_per_step = max_s / K * 1e3
     mean_ctx = (first_ctx + last_ctx) / 2
     result = {
@@ -624,7 +635,7 @@ def main():
             result["reference_triton"] = ref
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, B, int(round(mean_ctx)), args.dtype)
-    print(json.dumps(result), flush=True)
+    return result
 
 
 if __name__ == "__main__":

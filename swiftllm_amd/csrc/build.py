@@ -10,7 +10,6 @@ import concurrent.futures
 import os
 import shutil
 import subprocess
-import sys
 import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))

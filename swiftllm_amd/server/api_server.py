@@ -10,7 +10,6 @@ process down (reference api_server.py:114-119) so a supervisor can restart the r
 """
 import argparse
 import asyncio
-import json
 import os
 import traceback
 

@@ -9,7 +9,6 @@ no KV migration, no collective, nothing on xGMI (the reference h
 """
 import argparse
 import asyncio
-import json
 import os
 import subprocess
 import sys

@@ -22,9 +22,8 @@ The compute backend is libswiftllm_hip.so only; without a HIP device this class 
 import math
 import os
 import time
-from typing import List, Optional
+from typing import List
 
-import numpy as np
 import torch
 
 from swiftllm_amd import _hip

@@ -7,7 +7,7 @@ Runs bench.py's decode loop (Llama-3-8B dims, bf16, contexts centred at 1088) an
 section of LlamaModel.forward (plan / blocks / upload / launch / wait for the tokens) next to the step time, with hipGraph
 replay and with eager launches. "wait_tokens" is GPU time the host sleeps through; everything else is time the GPU may idle.
 """
-import argparse, json, os, sys, time
+import argparse, json, os, sys
 os.environ.setdefault("SWL_HOST_PROFILE", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -18,7 +18,6 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--steps", type=int, default=64)
     a = ap.parse_args()
-    args = bench.parse_args.__wrapped__() if hasattr(bench.parse_args, "__wrapped__") else None
     sys.argv = [sys.argv[0], "--batch", str(a.batch), "--kv-blocks", "4096"]
     args = bench.parse_args()
     cfg = bench.model_config_dict("llama3-8b")

@@ -14,7 +14,6 @@ import argparse
 import os
 import re
 import subprocess
-import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

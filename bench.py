@@ -505,21 +505,30 @@ def side_run_fresh_process(args, label):
 
 
 def main():
-    # stdout carries exactly ONE line — the JSON result of rank 0; everything the libraries print on the way
-    # ([Model.profile] ..., engine banners) goes to stderr
-    with contextlib.redirect_stdout(sys.stderr):
-        result = _run()
-    if result is not None:
-        print(json.dumps(result), flush=True)
-
-
-def _run():
     args = parse_args()
     from swiftllm_amd import dp
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: start the N ranks ourselves, one process per GPU; rank 0 prints the JSON line
-        with contextlib.redirect_stdout(sys.__stdout__):    # rank 0's line passes straight through
-            raise SystemExit(dp.spawn_local_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+        raise SystemExit(dp.spawn_local_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+    # stdout carries exactly ONE line — the JSON result of rank 0. Everything the libraries print on the way
+    # ([Model.profile] ..., gloo's connection banner from C++, engine banners) goes to stderr: file descriptor 1 itself
+    # points at stderr while the benchmark runs.
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        with contextlib.redirect_stdout(sys.stderr):
+            result = _run(args)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+    if result is not None:
+        print(json.dumps(result), flush=True)
+
+
+def _run(args):
+    from swiftllm_amd import dp
     rank, local_rank, world = dp.env_rank_world()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")

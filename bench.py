@@ -394,7 +394,7 @@ def cpu_baseline(cfg, batch, context, dtype):
                       num_cpu_blocks=0, max_seqs_in_block_table=batch, max_blocks_per_seq=blocks_per_seq + 2,
                       max_batch_size=batch, max_tokens_in_batch=batch * 16)
     eager_ops.linear = lambda a, w: torch.nn.functional.linear(a, w)    # native 16-bit CPU GEMM
-    ref = RefLlamaModel(LlamaModelConfig(small), ec, sd, tdtype)
+    ref = RefLlamaModel(LlamaModelConfig(small), ec, sd, tdtype, dense_decode_attention=True)
     ref.init_kvcache_and_swap(batch * blocks_per_seq)
     g = torch.Generator().manual_seed(1)
     ref.k_cache.copy_(torch.randn(ref.k_cache.shape, generator=g).to(tdtype))
@@ -423,7 +423,7 @@ def cpu_baseline(cfg, batch, context, dtype):
     full_step = per_layer * cfg["num_hidden_layers"] + rest
     return dict(value=round(batch / full_step, 3), unit="tokens/s", cores=torch.get_num_threads(), kind="port",
                 sample=(f"oracle/ref_model.py decode step, batch {batch}, contexts {first}..{first + steps - 1} (KV pool "
-                        f"filled directly, paged attention over the full context included), 1 of "
+                        f"filled directly, attention over the full context included — as one dense softmax per sequence), 1 of "
                         f"{cfg['num_hidden_layers']} layers timed ({per_layer * 1e3:.1f} ms/layer) + embedding/"
                         f"lm_head ({rest * 1e3:.1f} ms), recombined for {cfg['num_hidden_layers']} layers; "
                         f"{steps} steps, native 16-bit CPU GEMM"))

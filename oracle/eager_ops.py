@@ -189,6 +189,25 @@ def paged_attention(q, k_cache, v_cache, block_table, model_config, engine_confi
     paged_attention_phase2(mid_o, mid_lse, infer_state, o)
 
 
+def paged_attention_dense(q, k_cache, v_cache, block_table, model_config, engine_config, infer_state,
+                          cur_layer: int, o: torch.Tensor):
+    """The value paged_attention() computes — softmax(q.K^T * scale) V over each sequence's cached tokens, fp32, one
+    rounding — evaluated as ONE dense softmax per sequence instead of the reference kernel's walk over 16-token blocks and
+    sequence blocks (kernels/paged_attn.py:45-149). Same result up to fp32 reassociation (tests/test_oracle_golden.py holds
+    it to paged_attention); ~20x faster on a CPU because nothing loops in Python per block. Used where the oracle is
+    TIMED (bench.py's cpu_baseline leg): a baseline should measure the host's arithmetic, not the interpreter."""
+    bs = engine_config.block_size
+    G = model_config.num_q_heads // model_config.num_kv_heads
+    seq_ids = infer_state.seq_ids[infer_state.num_prefill_seqs:].tolist()
+    lens = infer_state.decoding_seq_lens.tolist()
+    for b in range(infer_state.num_decoding_seqs):
+        K = _gather_kv(k_cache, block_table, seq_ids[b], lens[b], cur_layer, bs).float()    # [KVH, len, D]
+        V = _gather_kv(v_cache, block_table, seq_ids[b], lens[b], cur_layer, bs).float()
+        qh = q[b].float().view(K.shape[0], G, -1)                                           # [KVH, G, D]
+        p = torch.softmax(torch.einsum("kgd,kld->kgl", qh, K) * infer_state.softmax_scale, dim=-1)
+        o[b] = torch.einsum("kgl,kld->kgd", p, V).reshape(o[b].shape).to(o.dtype)
+
+
 # ---- prefill attention ----------------------------------------------------------------------------------
 def prefill_attention(q, k, v, o, model_config, engine_config, infer_state):
     """kernels/prefill_attn.py:45-100 (and the vllm_flash_attn call it stands in for,

@@ -68,11 +68,13 @@ class RefLlamaModel:
     rounded (see eager_ops.paged_attention_phase1)."""
 
     def __init__(self, model_config, engine_config, state_dict: dict, dtype: torch.dtype,
-                 score_dtype: str = "fp32", tied_lm_head: bool = False):
+                 score_dtype: str = "fp32", tied_lm_head: bool = False, dense_decode_attention: bool = False):
         self.model_config = model_config
         self.engine_config = engine_config
         self.dtype = dtype
         self.score_dtype = score_dtype
+        # decode attention as one dense softmax per sequence (eager_ops.paged_attention_dense): for TIMING the oracle
+        self.dense_decode_attention = dense_decode_attention
         sd = {k: v.to(dtype) for k, v in state_dict.items()}
         self.wte = sd["model.embed_tokens.weight"]
         self.lm_head = self.wte if tied_lm_head else sd["lm_head.weight"]
@@ -124,8 +126,11 @@ class RefLlamaModel:
             ops.prefill_attention(q, k, v, o[:p], cfg, self.engine_config, st)
         if st.num_decoding_seqs > 0:
             ov = o[p:].view(-1, cfg.num_q_heads, cfg.head_dim)
-            ops.paged_attention(q[p:], self.k_cache, self.v_cache, bt, cfg, self.engine_config, st, i,
-                                ov, self.score_dtype)
+            if self.dense_decode_attention:
+                ops.paged_attention_dense(q[p:], self.k_cache, self.v_cache, bt, cfg, self.engine_config, st, i, ov)
+            else:
+                ops.paged_attention(q[p:], self.k_cache, self.v_cache, bt, cfg, self.engine_config, st, i,
+                                    ov, self.score_dtype)
         o = ops.linear(o, w.o_proj)
         ops.fused_add_rmsnorm_inplace(o, residual, w.ffn_norm, cfg.rms_norm_eps)
         up_gate = ops.linear(o, w.up_gate_proj)

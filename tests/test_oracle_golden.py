@@ -144,6 +144,23 @@ def test_paged_attention_matches_reference(golden, name, score_dtype, tol):
     assert err <= tol, err
 
 
+@pytest.mark.parametrize("name", ["gqa4_d128", "mha_d64", "gqa2_d32", "llama3_heads"])
+def test_dense_decode_attention_equals_the_blockwise_oracle(golden, name):
+    """eager_ops.paged_attention_dense (what bench.py's cpu_baseline leg times: one dense softmax per sequence) against the
+    block-walking restatement of the reference kernel on the golden inputs: the same value up to fp32 reassociation — at
+    most one rounding of the storage dtype apart — and within the golden's own tolerance of the reference's output."""
+    g = golden("paged_attention.pt")[name]
+    st = _paged_state(g)
+    mc = NS(num_q_heads=g["H"], num_kv_heads=g["KVH"], head_dim=g["D"], num_layers=g["L"])
+    ec = NS(block_size=g["block_size"])
+    want = torch.zeros_like(g["out"])
+    ops.paged_attention(g["q"], g["k_cache"], g["v_cache"], g["block_table"], mc, ec, st, g["layer"], want)
+    got = torch.zeros_like(g["out"])
+    ops.paged_attention_dense(g["q"], g["k_cache"], g["v_cache"], g["block_table"], mc, ec, st, g["layer"], got)
+    assert (got.float() - want.float()).abs().max().item() <= 2e-3
+    assert (got.float() - g["out"].float()).abs().max().item() <= 4e-3
+
+
 @pytest.mark.parametrize("score_dtype", ["fp32", "ref"])
 def test_whole_forward_matches_reference(golden, score_dtype):
     """RefLlamaModel vs the reference's LlamaModel.forward (fp16, BASELINE configs[0] model):

@@ -12,6 +12,7 @@ Operators come from oracle/eager_ops.py. Weights are passed in as a plain dict o
 tensors (the same dict tests write to safetensors for the product under test).
 """
 import itertools
+import copy
 import types
 
 import torch
@@ -107,6 +108,20 @@ class RefLlamaModel:
                                              ecfg.max_blocks_per_seq, ecfg.block_size)
         self.gpu_block_manager = mk("GPU", num_blocks)
         self.cpu_block_manager = mk("CPU", ecfg.num_cpu_blocks)
+
+    def fork(self, score_dtype: str = None):
+        """A second oracle continuing from this one's state (KV pool, swap pool, block tables): weights shared, state
+        copied. For tests that run one prompt pass and then several decode continuations with different score rounding
+        (the prompt pass does not depend on it: prefill attention has one rounding, eager_ops.prefill_attention)."""
+        other = copy.copy(self)
+        if score_dtype is not None:
+            other.score_dtype = score_dtype
+        for name in ("k_cache", "v_cache", "k_swap", "v_swap", "last_logits"):
+            t = getattr(self, name, None)
+            setattr(other, name, None if t is None else t.clone())
+        other.gpu_block_manager = copy.deepcopy(self.gpu_block_manager)
+        other.cpu_block_manager = copy.deepcopy(self.cpu_block_manager)
+        return other
 
     # ---- one transformer block (transformer_layer.py:31-130) ------------------------------------------
     def _layer(self, i, x, residual, st):

@@ -77,10 +77,9 @@ def test_full_width_forward_matches_oracle(tmp_path, case, dtype):
     kw = _engine_kw(batch, dtype)
 
     # ---- the checker: oracle with exact scores (teacher), and with the reference kernel's score rounding ----
-    def run_oracle(score_dtype, forced=None):
-        ref = RefLlamaModel(LlamaModelConfig(cfg), EngineConfig(model_path="", **kw), sd, tdtype, score_dtype=score_dtype)
-        ref.init_kvcache_and_swap(num_blocks)
-        toks, logits = [ref.forward(prompts, seq_ids, [])], [ref.last_logits.clone()]
+    # (one prompt pass: it does not depend on the decode-score rounding; the second oracle forks from its state)
+    def continue_oracle(ref, first_toks, forced=None):
+        toks, logits = [first_toks], [ref.last_logits.clone()]
         cur = list(lens)
         for s in range(steps):
             cur = [n + 1 for n in cur]
@@ -89,8 +88,13 @@ def test_full_width_forward_matches_oracle(tmp_path, case, dtype):
             logits.append(ref.last_logits.clone())
         return toks, logits
 
-    want_toks, want_logits = run_oracle("fp32")
-    noise_toks, noise_logits = run_oracle("ref", forced=want_toks)
+    teacher = RefLlamaModel(LlamaModelConfig(cfg), EngineConfig(model_path="", **kw), sd, tdtype, score_dtype="fp32")
+    teacher.init_kvcache_and_swap(num_blocks)
+    first = teacher.forward(prompts, seq_ids, [])
+    noisy = teacher.fork(score_dtype="ref")
+    want_toks, want_logits = continue_oracle(teacher, first)
+    noise_toks, noise_logits = continue_oracle(noisy, first, forced=want_toks)
+    del teacher, noisy
 
     # ---- the product ---------------------------------------------------------------------------------------
     synth.write_model_dir(str(tmp_path), cfg, sd)

@@ -206,3 +206,40 @@ def test_paged_attention_real_geometry_golden(golden):
     print("\n[reference noise floor at 32/8/128, ctx ~1k] oracle(ref scores) vs reference:", errs["ref"],
           " oracle(exact scores) vs reference:", errs["fp32"])
     assert errs["ref"] <= 1e-3 and errs["fp32"] <= 4e-3, errs
+
+
+def test_forked_oracle_continues_exactly_like_an_independent_one():
+    """RefLlamaModel.fork (one prompt pass shared by two decode continuations in the GPU parity tests): the fork with
+    the reference kernel's score rounding must produce bit for bit what a from-scratch oracle with that rounding does,
+    and must not disturb the oracle it was forked from."""
+    cfg = synth.make_config()
+    sd = synth.make_state_dict(cfg, seed=12)
+    ec = EngineConfig(model_path="", use_dummy=False, block_size=16, gpu_mem_utilization=0.9, num_cpu_blocks=0,
+                      max_seqs_in_block_table=4, max_blocks_per_seq=8, max_batch_size=3, max_tokens_in_batch=256)
+    g = torch.Generator().manual_seed(4)
+    lens = [37, 5, 16]
+    prompts = [torch.randint(0, cfg["vocab_size"], (n,), generator=g).tolist() for n in lens]
+
+    def fresh(score_dtype):
+        m = RefLlamaModel(LlamaModelConfig(cfg), ec, sd, torch.float16, score_dtype=score_dtype)
+        m.init_kvcache_and_swap(16)
+        return m, m.forward(prompts, [0, 1, 2], [])
+
+    def decode(m, toks, n=3):
+        out, cur = [], list(lens)
+        for _ in range(n):
+            cur = [c + 1 for c in cur]
+            toks = m.forward([[t] for t in toks], [0, 1, 2], list(cur))
+            out.append((list(toks), m.last_logits.clone()))
+        return out
+    teacher, first = fresh("fp32")
+    forked = teacher.fork(score_dtype="ref")
+    got_fork = decode(forked, first)
+    got_teacher = decode(teacher, first)          # after the fork ran: its state must be untouched by it
+    alone, first_alone = fresh("ref")
+    assert first_alone == first
+    for (ta, la), (tb, lb) in zip(got_fork, decode(alone, first_alone)):
+        assert ta == tb and torch.equal(la, lb)
+    exact, first_exact = fresh("fp32")
+    for (ta, la), (tb, lb) in zip(got_teacher, decode(exact, first_exact)):
+        assert ta == tb and torch.equal(la, lb)

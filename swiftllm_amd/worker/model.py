@@ -92,6 +92,9 @@ class LlamaModel:
         self._decode_graphs = {}     # (batch, split width, split count) -> _DecodeGraph, in LRU order
         self._lookahead = None       # _DecodeLookahead of the step that is expected next (graph replay only)
         self._decode_lookahead = True    # (tests switch it off to hold the fast path to the plain one)
+        # optional callable, invoked by forward() in the calling thread once the step's kernels are enqueued and before
+        # the host blocks on the sampled tokens (server/engine.py hides its per-request fan-out behind the running step)
+        self.after_launch_hook = None
         self._la_host = self._la_host_np = self._la_done = None
         self._eager_uses_graph_buckets = False   # tests: eager launches at the replay path's split geometry
         # SWL_HOST_PROFILE=1: wall-clock split of forward() on the host (plan / blocks / upload / launch / wait for the
@@ -406,6 +409,8 @@ class LlamaModel:
             self.gpu_block_manager.allocate_blocks_for_seqs(la.seq_ids, la.lens)
             tokens = self._forward_decode_graph(la.plan, la.dev)
             nxt = self._prepare_next_decode(la.plan, la.seq_ids, tokens)
+            if self.after_launch_hook is not None:
+                self.after_launch_hook()
             t4 = time.perf_counter() if prof is not None else 0.0
             out = tokens.tolist()
             if nxt is not None:
@@ -440,6 +445,8 @@ class LlamaModel:
             if pure_decode and not ignore_kvcache and self._eager_uses_graph_buckets:
                 plan.seq_block_size, plan.num_seq_blocks = self._graph_bucket(plan)
             tokens = self._forward(dev["input_ids"], self._make_infer_state(plan, dev, ignore_kvcache))
+        if self.after_launch_hook is not None:
+            self.after_launch_hook()
         if prof is None:
             out = tokens.tolist()
             if nxt is not None:

@@ -79,15 +79,18 @@ class Engine:
         return request
 
     async def add_request_and_stream(self, raw_request: RawRequest) -> AsyncGenerator[StepOutput, None]:
-        """Yield a StepOutput per generated token."""
+        """Yield a StepOutput per generated token. (Ends after `output_len` deliveries, not on
+        `request.is_finished()`: the request's own token list runs one step ahead of what has been fanned out.)"""
         request = self._enqueue(raw_request)
+        delivered = 0
         while True:
             step_output = await request.output_q.get()
             if step_output is None:     # rejected (request.error says why)
                 break
             yield step_output
             request.output_q.task_done()
-            if step_output.request.is_finished() and request.output_q.empty():
+            delivered += 1
+            if delivered >= request.output_len:
                 break
 
     async def add_request_and_wait(self, raw_request: RawRequest) -> Tuple[Request, List[int]]:

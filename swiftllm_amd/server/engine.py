@@ -1,18 +1,23 @@
-"""Engine — the asyncio control loop around one LlamaModel replica.
+"""Engine — the control loop around one LlamaModel replica.
 
 Public surface of the reference's swiftllm/server/engine.py:15-180: `initialize()`,
-`add_request_and_stream()`, `add_request_and_wait()`, `start_all_event_loops()`. Two cooperating loops:
-one tokenizes arrivals in batches and hands them to the scheduler, one asks the scheduler for the next
-batch, performs the swaps it orders, runs `LlamaModel.forward` in a worker thread (the event loop stays
-responsive while the GPU works) and fans the tokens out to per-request queues.
+`add_request_and_stream()`, `add_request_and_wait()`, `start_all_event_loops()`.
 
-The fan-out of step k (one queue put and one consumer wake-up per request: ~6 us each, ~200 us at batch 32) is not
-on the critical path: it is held back until step k+1 has been LAUNCHED — LlamaModel.forward calls
-`after_launch_hook` from the worker thread once its kernels are enqueued and before it blocks on the tokens — and
-then runs on the event loop while the GPU works. With nothing left to launch it runs at once.
+The reference runs scheduling on the asyncio loop and hands every `forward` to a thread pool
+(engine.py:121-176): two thread wake-ups per decode step (the pool worker, then the event loop: ~170 us when
+both slept through a 4 ms step) plus the per-request fan-out (one queue put and one consumer wake-up per
+request, ~6 us each) between one step's tokens and the next step's launch — 450-650 us per iteration against a
+4 ms decode step (`tools/engine_overhead.py`). Here the critical loop lives on ONE dedicated model thread that
+never sleeps while there is work: arrivals are drained from a thread-safe inbox, the scheduler picks the batch,
+`LlamaModel.forward` runs in place, and the fan-out of step k is posted to the event loop only when step k+1 has
+been LAUNCHED (`LlamaModel.after_launch_hook`, called once the kernels are enqueued and before the host blocks on
+the tokens) — it runs on the asyncio thread while the GPU works. The asyncio side keeps what belongs there:
+tokenization of arrivals, per-request queues and events, the HTTP layer.
 """
 import asyncio
 import functools
+import queue
+import threading
 from typing import AsyncGenerator, List, Optional, Tuple
 
 from swiftllm_amd.engine_config import EngineConfig
@@ -38,7 +43,11 @@ class Engine:
         self.tokenization_engine = None
         self.untokenized_raw_requests: List[Tuple[Request, RawRequest]] = []
         self.num_forwards = 0
-        self._undelivered: List[Tuple[Request, int]] = []    # (request, token) of the last step, not yet fanned out
+        # asyncio thread -> model thread: lists of servable requests (the scheduler is touched by the model thread only)
+        self._inbox: "queue.SimpleQueue[List[Request]]" = queue.SimpleQueue()
+        # model thread only: (request, token, finished) of the last step, not fanned out yet
+        self._undelivered: List[Tuple[Request, int, bool]] = []
+        self._stop = threading.Event()
 
     async def _run_on_model_async(self, func, *args, **kwargs):
         return await self.event_loop.run_in_executor(None, functools.partial(func, *args, **kwargs))
@@ -68,7 +77,7 @@ class Engine:
             self.scheduler.max_seq_len = int(rope.shape[0])     # not left to raise inside forward mid-flight
         self.tokenization_engine = TokenizationEngine(self.engine_config)
         if hasattr(self.model, "after_launch_hook"):
-            self.model.after_launch_hook = self._on_forward_launched
+            self.model.after_launch_hook = self._post_undelivered
         self.initialized = True
         print("[Engine] Model initialized")
 
@@ -99,7 +108,7 @@ class Engine:
         await request.finished_event.wait()
         return request, request.output_token_ids
 
-    # ---- loops ------------------------------------------------------------------------------------------------
+    # ---- asyncio side -------------------------------------------------------------------------------------------
     async def _tokenize_raw_request_event_loop(self):
         while True:
             if not self.untokenized_raw_requests:
@@ -114,38 +123,58 @@ class Engine:
                     req.prompt_len = len(token_ids)
             servable = []
             for req, _ in pending:
-                req.error = self.scheduler.why_unservable(req)
+                req.error = self.scheduler.why_unservable(req)      # (reads the engine's limits only)
                 if req.error is None:
                     servable.append(req)
                 else:           # answer at once: waiters wake up with no tokens, streams end
                     req.finished_event.set()
                     req.output_q.put_nowait(None)
-            self.scheduler.on_requests_arrival(servable)
+            if servable:
+                self._inbox.put(servable)
             await asyncio.sleep(0.001)
 
-    def _deliver(self):
-        """Fan the held-back tokens out (event-loop thread only; idempotent)."""
-        pending, self._undelivered = self._undelivered, []
-        for req, tok in pending:
+    @staticmethod
+    def _deliver(outputs: List[Tuple[Request, int, bool]]):
+        """Fan one step's tokens out to the per-request queues and events (event-loop thread)."""
+        for req, tok, finished in outputs:
             req.output_q.put_nowait(StepOutput(tok, req))
-            if req.is_finished():
+            if finished:
                 req.finished_event.set()
 
-    def _on_forward_launched(self):
-        """LlamaModel.after_launch_hook: runs in the worker thread, right after the step's kernels were enqueued."""
-        self.event_loop.call_soon_threadsafe(self._deliver)
+    # ---- model thread ---------------------------------------------------------------------------------------------
+    def _post_undelivered(self):
+        """Hand the held-back tokens to the event loop. Called on the model thread: by LlamaModel.forward right after
+        a step's kernels were enqueued (`after_launch_hook`), and by `_iterate` when nothing will be launched."""
+        if not self._undelivered:
+            return
+        outputs, self._undelivered = self._undelivered, []
+        try:
+            self.event_loop.call_soon_threadsafe(self._deliver, outputs)
+        except RuntimeError:        # the event loop is gone (shutdown): nobody is listening any more
+            pass
 
-    async def step(self) -> bool:
-        """One scheduling iteration; False when there was nothing to do."""
+    def _drain_inbox(self, wait_s: float = 0.0):
+        try:
+            if wait_s > 0.0:
+                self.scheduler.on_requests_arrival(self._inbox.get(timeout=wait_s))
+            while True:
+                self.scheduler.on_requests_arrival(self._inbox.get_nowait())
+        except queue.Empty:
+            pass
+
+    def _iterate(self) -> bool:
+        """One scheduling iteration, start to finish, on the calling (model) thread; False when there was nothing
+        to do. Reference: engine.py:121-176."""
+        self._drain_inbox()
         batch, swap_in, swap_out = self.scheduler.get_next_batch()
         if not batch:
-            self._deliver()     # no launch to hide behind
+            self._post_undelivered()        # no launch to hide the fan-out behind
             if not swap_in and not swap_out:
                 return False
         if swap_out:
-            await self._run_on_model_async(self.model.swap_out_seqs, [r.request_id for r in swap_out])
+            self.model.swap_out_seqs([r.request_id for r in swap_out])
         if swap_in:
-            await self._run_on_model_async(self.model.swap_in_seqs, [r.request_id for r in swap_in])
+            self.model.swap_in_seqs([r.request_id for r in swap_in])
         if batch:
             # prefill sequences first (the scheduler orders them so), their whole prompt; decoding ones
             # bring their last token and their length INCLUDING it
@@ -153,24 +182,62 @@ class Engine:
             seq_ids = [r.request_id for r in batch]
             decoding_lens = [r.num_tokens() for r in batch if not r.is_prefill_stage()]
             try:
-                tokens = await self._run_on_model_async(self.model.forward, input_ids, seq_ids, decoding_lens)
+                tokens = self.model.forward(input_ids, seq_ids, decoding_lens)
             finally:
-                self._deliver()     # (a data plane without the hook, or a forward that raised before launching)
+                self._post_undelivered()    # (a data plane without the hook, or a forward that raised before launching)
             self.num_forwards += 1
+            outputs, finished = [], []
             for req, tok in zip(batch, tokens):
                 req.output_token_ids.append(tok)
-            finished = [r.request_id for r in batch if r.is_finished()]
+                done = req.is_finished()
+                outputs.append((req, tok, done))
+                if done:
+                    finished.append(req.request_id)
             if finished:
                 # release KV blocks before anyone is told: a caller that sees "finished" may tear us down
-                await self._run_on_model_async(self.model.free_seqs_resources, finished)
-            self._undelivered = list(zip(batch, tokens))
+                self.model.free_seqs_resources(finished)
+            self._undelivered = outputs
             self.scheduler.on_batch_finish(batch)
         return True
 
+    def _model_loop(self, failed: "asyncio.Future"):
+        try:
+            while not self._stop.is_set():
+                if not self._iterate():
+                    self._drain_inbox(wait_s=0.005)     # idle: block on the inbox (wakes at once on an arrival)
+            self._post_undelivered()
+        except BaseException as exc:     # noqa: BLE001 — surfaces in start_all_event_loops(), as in the reference
+            def report(exc=exc):
+                if not failed.done():
+                    failed.set_exception(exc)
+            try:
+                self.event_loop.call_soon_threadsafe(report)
+            except RuntimeError:
+                pass
+
+    async def step(self) -> bool:
+        """One scheduling iteration (single-stepping for tests and tools; the serving loop is `_model_loop`). Its
+        tokens are fanned out before it returns. False when there was nothing to do."""
+        def one():
+            did = self._iterate()
+            self._post_undelivered()
+            return did
+        did = await self._run_on_model_async(one)
+        await asyncio.sleep(0)      # the posted fan-out runs before the caller continues
+        return did
+
     async def _main_event_loop(self):
-        while True:
-            if not await self.step():
-                await asyncio.sleep(0.005)
+        """Owns the model thread: starts it, re-raises what it dies of, stops it when cancelled."""
+        self._stop.clear()
+        failed = self.event_loop.create_future()
+        thread = threading.Thread(target=self._model_loop, args=(failed,), name="swiftllm-model", daemon=True)
+        thread.start()
+        try:
+            await failed
+        finally:
+            self._stop.set()
+            self._inbox.put([])     # wake it if it is waiting for arrivals
+            thread.join(10.0)       # (at most the step in flight)
 
     async def start_all_event_loops(self):
         assert self.initialized, "Engine not initialized. Please call `initialize()` before starting the event loop."

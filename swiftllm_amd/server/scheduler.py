@@ -59,7 +59,9 @@ class Scheduler:
         return cdiv(req.num_tokens() + extra_tokens, self.engine_config.block_size)
 
     def _running_blocks(self) -> int:
-        return sum(self._blocks(r) for r in self.running_q)
+        # (once per decode iteration over the whole running set: spelled out, no per-request method calls)
+        bs = self.engine_config.block_size
+        return sum((r.prompt_len + len(r.output_token_ids) + bs - 1) // bs for r in self.running_q)
 
     # ---- events --------------------------------------------------------------------------------------
     def why_unservable(self, req: Request) -> Optional[str]:
@@ -128,6 +130,8 @@ class Scheduler:
     def _admit_prefills(self) -> List[Request]:
         ecfg = self.engine_config
         batch: List[Request] = []
+        if not self.waiting_q:
+            return batch
         blocks = self._running_blocks()
         tokens = 0
         while self.waiting_q:

@@ -158,6 +158,72 @@ def test_engine_generates_streams_and_frees(piggyback):
         assert all(not (isinstance(c[0], int) and c[0] > 0 and c[1] > 0) for c in model.calls)
 
 
+class HookedModel(FakeModel):
+    """A data plane with LlamaModel's `after_launch_hook`: fires it once its "kernels are enqueued", then "waits for
+    the GPU" (GIL released) before returning the tokens. Records what the clients had seen at both moments."""
+
+    def __init__(self, seen):
+        super().__init__()
+        self.after_launch_hook = None
+        self.seen = seen            # tokens the streaming client has received so far (appended on the event loop)
+        self.log = []
+
+    def forward(self, input_ids, seq_ids, decoding_lens):
+        import time
+        before = len(self.seen)
+        if self.after_launch_hook is not None:
+            self.after_launch_hook()
+        time.sleep(0.02)            # the step "runs": the event loop has all the time it needs for the fan-out
+        self.log.append((before, len(self.seen)))
+        return super().forward(input_ids, seq_ids, decoding_lens)
+
+
+def test_engine_fans_a_step_out_behind_the_next_launch():
+    """The tokens of step k reach the client while step k+1 runs (posted by after_launch_hook), not before its launch
+    and not after its end; the last token is delivered without a further launch; the model thread ends with the loops."""
+    import threading
+    seen = []
+
+    async def run():
+        model = HookedModel(seen)
+        eng = Engine(_cfg(), model=model)
+        await eng.initialize()
+        assert model.after_launch_hook is not None
+        loops = asyncio.ensure_future(eng.start_all_event_loops())
+
+        async def stream():
+            async for s in eng.add_request_and_stream(RawRequest("", 5, [3, 4])):
+                seen.append(s.token_id)
+        await asyncio.wait_for(stream(), timeout=20)
+        assert any(t.name == "swiftllm-model" for t in threading.enumerate())
+        loops.cancel()
+        await asyncio.gather(loops, return_exceptions=True)
+        return model
+    model = asyncio.run(run())
+    assert seen == _expected([3, 4], 5)
+    # forward k (k = 0..4) was entered with k-1 tokens delivered (none for k <= 1: token k-1 is posted by ITS launch)
+    # and left with k tokens delivered
+    assert model.log == [(0, 0), (0, 1), (1, 2), (2, 3), (3, 4)]
+    assert not any(t.name == "swiftllm-model" and t.is_alive() for t in threading.enumerate())
+
+
+def test_engine_surfaces_a_failing_data_plane():
+    """An exception on the model thread ends start_all_event_loops() with that exception (the reference's engine dies
+    the same way, engine.py:121-176) instead of leaving the server answering nothing."""
+    class Broken(FakeModel):
+        def forward(self, input_ids, seq_ids, decoding_lens):
+            raise RuntimeError("HIP error: the device fell over")
+
+    async def run():
+        eng = Engine(_cfg(), model=Broken())
+        await eng.initialize()
+        loops = asyncio.ensure_future(eng.start_all_event_loops())
+        asyncio.ensure_future(eng.add_request_and_wait(RawRequest("", 3, [1, 2])))
+        with pytest.raises(RuntimeError, match="the device fell over"):
+            await asyncio.wait_for(loops, timeout=20)
+    asyncio.run(run())
+
+
 def test_engine_idles_without_calling_the_model():
     async def run():
         model = FakeModel()

@@ -48,6 +48,7 @@ class Engine:
         # model thread only: (request, token, finished) of the last step, not fanned out yet
         self._undelivered: List[Tuple[Request, int, bool]] = []
         self._stop = threading.Event()
+        self._model_thread: Optional[threading.Thread] = None
 
     async def _run_on_model_async(self, func, *args, **kwargs):
         return await self.event_loop.run_in_executor(None, functools.partial(func, *args, **kwargs))
@@ -218,6 +219,9 @@ class Engine:
     async def step(self) -> bool:
         """One scheduling iteration (single-stepping for tests and tools; the serving loop is `_model_loop`). Its
         tokens are fanned out before it returns. False when there was nothing to do."""
+        if self._model_thread is not None and self._model_thread.is_alive():
+            raise RuntimeError("Engine.step() while the serving loop runs: the scheduler belongs to the model thread")
+
         def one():
             did = self._iterate()
             self._post_undelivered()
@@ -231,6 +235,7 @@ class Engine:
         self._stop.clear()
         failed = self.event_loop.create_future()
         thread = threading.Thread(target=self._model_loop, args=(failed,), name="swiftllm-model", daemon=True)
+        self._model_thread = thread
         thread.start()
         try:
             await failed

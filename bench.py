@@ -479,6 +479,42 @@ def side_run(args, model_name, batch, context, steps, warmup, label, model=None)
     return out
 
 
+def mixed_step_run(model, cfg, batch, prompt_len, context, n_prefill=4, reps=5):
+    """The batch shape BASELINE configs[2] names ("piggybacked prefill+decode"): `n_prefill` fresh prompt_len-token
+    prompts and `batch - n_prefill` sequences decoding at ~`context` in ONE forward — what the scheduler emits with
+    piggyback=True; the data plane runs the decodes' paged attention on a side stream next to the prompts' flash attention
+    (transformer_layer.py) — against the same prompts alone and the same decodes alone. Medians of `reps` forwards each,
+    host-synchronised (mixed and prompt-only forwards are eager launches; the decode-only one replays its hipGraph)."""
+    import statistics
+    import torch
+    g = torch.Generator().manual_seed(11)
+    vocab = cfg["vocab_size"]
+    pre_ids, dec_ids = list(range(n_prefill)), list(range(n_prefill, batch))
+    prompts = [torch.randint(0, vocab, (prompt_len,), generator=g).tolist() for _ in pre_ids]
+    toks = torch.randint(0, vocab, (len(dec_ids),), generator=g).tolist()
+    lens = [context - 2 * reps - 4] * len(dec_ids)        # KV as it lies in the (N(0,1)-filled) pool, as side_run
+    t = {"decode_only": [], "prefill_only": [], "mixed": []}
+    for rep in range(reps + 1):                            # (rep 0: warm-up — graph capture, GEMM heuristics)
+        lens = [n + 1 for n in lens]
+        toks, dt = timed(lambda: model.forward([[x] for x in toks], dec_ids, lens))
+        t["decode_only"].append(dt)
+        _, dt = timed(lambda: model.forward(prompts, pre_ids, []))
+        t["prefill_only"].append(dt)
+        model.free_seqs_resources(pre_ids)
+        lens = [n + 1 for n in lens]
+        out, dt = timed(lambda: model.forward(prompts + [[x] for x in toks], pre_ids + dec_ids, lens))
+        t["mixed"].append(dt)
+        toks = out[n_prefill:]
+        model.free_seqs_resources(pre_ids)
+    model.free_seqs_resources(dec_ids)
+    ms = {k: statistics.median(v[1:]) * 1e3 for k, v in t.items()}
+    return dict(workload=f"{n_prefill} x {prompt_len}-token prompts + {len(dec_ids)} decodes at context ~{context} in one forward",
+                mixed_ms=round(ms["mixed"], 3), prefill_only_ms=round(ms["prefill_only"], 3),
+                decode_only_ms=round(ms["decode_only"], 3),
+                mixed_over_separate=round(ms["mixed"] / (ms["prefill_only"] + ms["decode_only"]), 4),
+                tokens_per_s=round((n_prefill * prompt_len + len(dec_ids)) / ms["mixed"] * 1e3, 1), reps=reps)
+
+
 def side_run_fresh_process(args, label):
     """configs[3] as its own `bench.py --model llama2-7b --batch 4 --prompt-len 16384 --gen-len 64 --skip-prefill` run in
     a child process (this process has released its model): the 47 GB a step streams then sit in a freshly mapped
@@ -626,6 +662,12 @@ def _run(args):
             result["eager"] = dict(ms_per_step=round(dt / K * 1e3, 4), value=round(B * K / dt, 1), contexts=[f2, l2],
                                    note="hipGraph replay off: one HIP launch per kernel from Python")
         run.release()
+        if B > 4:
+            try:
+                result["piggyback_mixed_step"] = mixed_step_run(model, cfg, B, S, S + GEN // 2)
+            except Exception as exc:     # noqa: BLE001 — a side measurement must never take the bench line down
+                print(f"[bench] mixed-step side run failed ({type(exc).__name__}: {exc})", file=sys.stderr)
+                model.free_seqs_resources(list(range(B)))
         if args.model == "llama3-8b":
             result["configs1_batch1"] = side_run(args, "llama3-8b", 1, 1024 + GEN // 2, 48, 8,
                                                  "BASELINE.json configs[1]: batch 1 decode-only", model=model)

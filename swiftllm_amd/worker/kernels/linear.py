@@ -133,7 +133,44 @@ def linear(a: torch.Tensor, w: torch.Tensor, skinny: bool = False) -> torch.Tens
                   ws.numel() * 4 if ws is not None else 0, m, n, k, _row_stride(a), n, 0,
                   _hip.dtype_code(a.dtype), _hip.stream())
         return out
-    return F.linear(a, w)
+    return _blas_linear(a, w)
+
+
+# hipBLASLt's cost per token is far from flat in the token count M (Llama-3-8B widths, bf16, MI355X,
+# profiles/r03_prefill_gemm_m_sweep.md): 1.52 / 1.58 / 1.57 PF at M = 4096 / 8192 / 16384 and 1.54-1.56 PF on the multiples
+# of 4096 above, but 1.06-1.14 PF from 4097 to 4608 (the down projection alone 708 instead of 295 us), 1.16-1.2 PF around
+# 5.5k, 6.5k, 7.5k, 1.26 PF at 10240. A prompt pass (or a piggybacked batch: 4 x 1024 prompt tokens + 28 decodes = 4124
+# rows ran 24 % SLOWER than the two forwards apart) must not depend on where its token count happens to fall. Above
+# 4096 rows the product is therefore taken in row blocks of sizes the library is good at, each block one BLAS call
+# writing its rows of the result in place: from 16384 rows on, the largest multiple of 4096 in one call (the plateau);
+# below, 8192 while that many rows remain, then 4096; then the remainder (< 4096 rows, a range without cliffs). Rows are
+# independent, so this is the same product up to the order of a row's K-sum, which already depended on which rows shared
+# a launch.
+_BLAS_ROW_BLOCKS = (8192, 4096)
+_BLAS_PLATEAU_ROWS = 16384
+
+
+def _blas_linear(a: torch.Tensor, w: torch.Tensor, row_blocks=None, plateau=None) -> torch.Tensor:
+    blocks = _BLAS_ROW_BLOCKS if row_blocks is None else row_blocks
+    if a.dim() != 2 or not blocks or a.shape[0] <= min(blocks):
+        return F.linear(a, w)
+    plateau = _BLAS_PLATEAU_ROWS if plateau is None else plateau
+    m, unit = a.shape[0], min(blocks)
+    if m >= plateau and m % unit == 0:
+        return F.linear(a, w)
+    out = torch.empty((m, w.shape[0]), dtype=a.dtype, device=a.device)
+    wt = w.t()
+    start = 0
+    if m >= plateau:
+        start = m // unit * unit
+        torch.mm(a[:start], wt, out=out[:start])
+    for size in sorted(blocks, reverse=True):
+        while m - start >= size:
+            torch.mm(a[start:start + size], wt, out=out[start:start + size])
+            start += size
+    if start < m:
+        torch.mm(a[start:], wt, out=out[start:])
+    return out
 
 
 def linear_splitk(a: torch.Tensor, w: torch.Tensor, always: bool = False):

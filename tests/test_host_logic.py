@@ -480,3 +480,37 @@ def test_decode_lookahead_is_taken_only_by_the_exact_continuation():
     assert m._take_lookahead(ids, [4, 0, 2], [11, 21, 31], False) is None
     m, _ = fresh(tokens=None)
     assert m._take_lookahead(ids, [4, 0, 2], [11, 21, 31], False) is None
+
+
+def test_blas_row_blocks_cover_every_row_once():
+    """kernels/linear.py: prompt-sized products are taken in row blocks of the sizes hipBLASLt is good at (8192, 4096,
+    remainder); here with toy block sizes on the CPU: the blocked product is the plain one (to fp32 summation order), for token counts around
+    every block boundary, and small inputs are left to a single call."""
+    import torch
+    import torch.nn.functional as F
+    import importlib
+    L = importlib.import_module("swiftllm_amd.worker.kernels.linear")     # (the package re-exports the function)
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(24, 16, generator=g)
+    for m in (1, 4, 5, 8, 9, 12, 13, 16, 17, 20, 21, 29):
+        a = torch.randn(m, 16, generator=g)
+        got = L._blas_linear(a, w, row_blocks=(8, 4), plateau=16)
+        assert got.shape == (m, 24)
+        # (same products and sums per row; a BLAS may order a row's K-sum differently for another block height)
+        torch.testing.assert_close(got, F.linear(a, w), rtol=1e-5, atol=1e-5)
+    calls = []
+    real = torch.mm
+    try:
+        torch.mm = lambda x, y, out=None: (calls.append(x.shape[0]), real(x, y, out=out))[1]
+        L._blas_linear(torch.randn(15, 16, generator=g), w, row_blocks=(8, 4), plateau=16)
+        assert calls == [8, 4, 3]
+        calls.clear()
+        L._blas_linear(torch.randn(29, 16, generator=g), w, row_blocks=(8, 4), plateau=16)
+        assert calls == [28, 1]             # past the plateau: the whole multiple of the smallest block at once
+        calls.clear()
+        for m in (4, 16, 32):               # at or below the smallest block / on the plateau's grid: one plain call
+            L._blas_linear(torch.randn(m, 16, generator=g), w, row_blocks=(8, 4), plateau=16)
+        assert calls == []
+    finally:
+        torch.mm = real
+    assert L._BLAS_ROW_BLOCKS == (8192, 4096) and L._BLAS_PLATEAU_ROWS == 16384

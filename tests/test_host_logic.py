@@ -514,3 +514,36 @@ def test_blas_row_blocks_cover_every_row_once():
     finally:
         torch.mm = real
     assert L._BLAS_ROW_BLOCKS == (8192, 4096) and L._BLAS_PLATEAU_ROWS == 16384
+
+
+def test_block_planner_arithmetic_and_fixed_rule_mirror():
+    """tools/blas_block_planner.py: `plan` finds the cheapest cover of M rows from a cost table (checked against brute
+    force on a small grid, cliffs included), and `fixed_rule` is exactly the split kernels/linear.py ships."""
+    import importlib
+    import itertools
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    P = importlib.import_module("blas_block_planner")
+    cost = {4: 10.0, 8: 14.0, 12: 40.0, 16: 26.0, 20: 60.0}         # a cliff at 12 and at 20
+    for m in range(1, 41):
+        pred, blocks = P.plan(cost, m, 4)
+        assert sum(blocks) == m and all(b > 0 for b in blocks)
+        units = -(-m // 4)
+        brute = min(sum(cost[b] for b in combo)
+                    for r in range(1, units + 1)
+                    for combo in itertools.combinations_with_replacement(sorted(cost), r)
+                    if sum(combo) == units * 4)
+        assert abs(pred - brute) < 1e-9, (m, pred, brute)
+    assert P.plan(cost, 12, 4) == (24.0, [8, 4])                     # steps around the cliff
+    L = importlib.import_module("swiftllm_amd.worker.kernels.linear")
+    w = torch.zeros(4, 8)
+    real, calls = torch.mm, []
+    try:
+        torch.mm = lambda x, y, out=None: (calls.append(x.shape[0]), real(x, y, out=out))[1]
+        for m in (1, 4096, 4097, 4124, 8191, 8192, 8193, 12288, 13000, 16383, 16384, 16385, 17000, 32768, 32796):
+            calls.clear()
+            L._blas_linear(torch.zeros(m, 8), w)
+            assert (calls or [m]) == P.fixed_rule(m), m
+    finally:
+        torch.mm = real

@@ -224,6 +224,52 @@ def test_engine_surfaces_a_failing_data_plane():
     asyncio.run(run())
 
 
+@pytest.mark.parametrize("piggyback", [False, True])
+def test_engine_under_churn_delivers_every_token_in_order(piggyback):
+    """40 requests of random lengths arriving in waves, streamed and awaited, on a pool of 8 blocks (swaps happen) and a
+    data plane with the launch hook: every stream carries exactly its generation, in order; every request is freed once;
+    swap-ins and swap-outs pair up."""
+    import random
+    rng = random.Random(5)
+    shapes = [([rng.randrange(90) for _ in range(rng.randint(1, 30))], rng.randint(1, 12)) for _ in range(40)]
+
+    async def run():
+        model = HookedModel([])
+        model.num_blocks = 8
+        eng = Engine(_cfg(max_batch_size=5), model=model, piggyback=piggyback)
+        await eng.initialize()
+        loops = asyncio.ensure_future(eng.start_all_event_loops())
+
+        async def stream(p, n):
+            return [s.token_id async for s in eng.add_request_and_stream(RawRequest("", n, p))]
+
+        async def wait(p, n):
+            return (await eng.add_request_and_wait(RawRequest("", n, p)))[1]
+        tasks = []
+        for i, (p, n) in enumerate(shapes):
+            tasks.append(asyncio.ensure_future((stream if i % 2 else wait)(p, n)))
+            if i % 7 == 6:
+                await asyncio.sleep(0.05)       # the next wave arrives while the first is being served
+        got = await asyncio.wait_for(asyncio.gather(*tasks), timeout=60)
+        loops.cancel()
+        await asyncio.gather(loops, return_exceptions=True)
+        return model, got
+
+    import time
+    real_sleep = time.sleep
+    time.sleep = lambda s: real_sleep(min(s, 0.0005))       # (HookedModel's 20 ms "GPU time" would make this 10 s)
+    try:
+        model, got = asyncio.run(run())
+    finally:
+        time.sleep = real_sleep
+    for (p, n), toks in zip(shapes, got):
+        assert toks == _expected(p, n)
+    assert len(model.freed) == len(shapes) and len(set(model.freed)) <= 16
+    outs = sum(len(c[1]) for c in model.calls if c[0] == "out")
+    ins = sum(len(c[1]) for c in model.calls if c[0] == "in")
+    assert outs == ins and outs > 0         # the small pool did force swapping
+
+
 def test_engine_idles_without_calling_the_model():
     async def run():
         model = FakeModel()

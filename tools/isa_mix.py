@@ -46,6 +46,7 @@ def main():
     ap.add_argument("src")
     ap.add_argument("--kernel", required=True)
     ap.add_argument("--seq", action="store_true")
+    ap.add_argument("--ops", action="store_true", help="opcode histogram of the largest loop")
     ap.add_argument("-D", dest="defines", action="append", default=[])
     ap.add_argument("--min", type=int, default=40, help="ignore loops with fewer instructions")
     a = ap.parse_args()
@@ -88,6 +89,11 @@ def main():
         print(f"  loop [{lo}, {hi}] {len(seq)} instr: " + " ".join(f"{k}={v}" for k, v in cnt.items() if v))
         if best is None or len(seq) > len(best[2]):
             best = (lo, hi, seq)
+    if a.ops and best:
+        import collections
+        hist = collections.Counter(op for op, _ in insts[best[0]:best[1] + 1])
+        for op, n in hist.most_common():
+            print(f"    {n:4d}  {op}")
     if a.seq and best:
         s = "".join(best[2])
         for i in range(0, len(s), 120):

@@ -206,34 +206,149 @@ def cmd_bench(args):
     print(json.dumps(out), flush=True)
 
 
+def _ulp_of(x, dtype_name: str):
+    import torch
+    mant = 10 if dtype_name == "float16" else 7
+    return torch.exp2(torch.floor(torch.log2(x.abs().clamp(min=2.0 ** -14))) - mant)
+
+
+def planned_step(model, logits_log, ids, seq_ids, dec_lens, split=1, reverse=False):
+    """One scripted step as `split` forward() calls (sequence i goes to call i % split), optionally with the sequences of
+    each group in reverse order; forward() wants prefill sequences before decoding ones, so the order is changed inside
+    the two groups only. `logits_log` is the list the lm_head tap appends to. Returns (tokens, logits [B, V]) in the
+    SCRIPT's sequence order whatever the plan."""
+    import torch
+    n, n_dec = len(seq_ids), len(dec_lens)
+    n_pre = n - n_dec
+    pre, dec = list(range(n_pre)), list(range(n_pre, n))
+    if reverse:
+        pre, dec = pre[::-1], dec[::-1]
+    toks, logits = [None] * n, [None] * n
+    for c in range(max(1, split)):
+        chunk = pre[c::split] + dec[c::split] if split > 1 else pre + dec
+        if not chunk:
+            continue
+        del logits_log[:]
+        t = model.forward([ids[i] for i in chunk], [seq_ids[i] for i in chunk], [dec_lens[i - n_pre] for i in chunk if i >= n_pre])
+        lg = logits_log[-1]
+        for j, i in enumerate(chunk):
+            toks[i], logits[i] = t[j], lg[j]
+    return toks, torch.stack(logits)
+
+
 def cmd_forward(args):
     """in.pt: dict(config=HF config dict, model_path=dir with safetensors, num_blocks, max_len,
-    steps=[dict(input_ids, seq_ids, dec_lens)]). out.pt: per step tokens + pre-argmax logits (fp32, CPU)."""
+    steps=[dict(input_ids, seq_ids, dec_lens)]). out.pt: per step tokens + pre-argmax logits (fp32, CPU).
+
+    Optional keys: `logits` ("fp32" | "storage" | "none"), `logits_steps` (step indices whose full logits are returned; default
+    all) and `variants` — the REFERENCE-VS-ITSELF control. Each variant re-runs the same script on the
+    same weights under an execution plan that changes nothing in exact arithmetic:
+        seq_block_size=N   the flash-decoding split width (model.py:305-324 picks one by heuristic; any power of two >= 64
+                           is a legal value of the same kernel, paged_attn.py:35-108) — other partial-softmax merges;
+        split=k            the batch as k forward() calls of batch/k sequences each — other GEMM row counts, hence other
+                           hipBLASLt kernels / K-split orders;
+        reverse=True       the sequences in reverse order.
+    For each variant: the script teacher-forced with the base run's tokens (logit distance and greedy-id mismatches at
+    identical histories) and free-running (sequences identical to the end). Summaries go to <out>.variants.json; nothing of
+    the reference's arithmetic is touched — only which legal plan it runs."""
     import torch
     job = torch.load(args.inp)
-    swiftllm = load_reference(job.get("dtype", "float16"))
+    dtype_name = job.get("dtype", "float16")
+    swiftllm = load_reference(dtype_name)
     from swiftllm.worker.layers import post_layer as post_mod
     logits_log = []
     orig_linear = post_mod.linear
 
     keep = job.get("logits", "fp32")     # "fp32" | "storage" (exact, half the bytes) | "none"
+    keep_steps = job.get("logits_steps")
+    variants = job.get("variants") or []
 
     def tapped_linear(a, w):
         r = orig_linear(a, w)
-        logits_log.append(None if keep == "none" else (r.cpu() if keep == "storage" else r.float().cpu()))
+        logits_log.append(r)
         return r
     post_mod.linear = tapped_linear     # the only linear() in post_layer.py is lm_head (:38)
     batch = max(len(s["seq_ids"]) for s in job["steps"])
     model = _build_model(swiftllm, job["config"], job["model_path"], False, batch, job["max_len"], job["num_blocks"])
+    plan = dict(seq_block_size=None)
+    inner_forward = model._forward
+
+    def planned_forward(ids, st):
+        sbs = plan["seq_block_size"]
+        if sbs and st.num_decoding_seqs > 0:
+            st.seq_block_size = sbs
+            st.num_seq_blocks = (st.max_decoding_len + sbs - 1) // sbs
+        return inner_forward(ids, st)
+    model._forward = planned_forward
+
+    def run_step(ids, seq_ids, dec_lens, split=1, reverse=False):
+        return planned_step(model, logits_log, ids, seq_ids, dec_lens, split, reverse)
+
+    def run_script(forced=None, **kw):
+        all_toks, all_logits = [], []
+        for si, s in enumerate(job["steps"]):
+            ids = s["input_ids"]
+            if ids is None:     # "feed back what you sampled": decode continuation
+                ids = [[t] for t in (forced[si - 1] if forced is not None else all_toks[-1])]
+            t, lg = run_step(ids, s["seq_ids"], s["dec_lens"], **kw)
+            all_toks.append(t)
+            all_logits.append(lg)
+        seqs = sorted({i for s in job["steps"] for i in s["seq_ids"]})
+        model.free_seqs_resources(seqs)
+        return all_toks, all_logits
+
+    base_toks, base_logits = run_script()
     res = []
-    for s in job["steps"]:
-        ids = s["input_ids"]
-        if ids is None:     # "feed back what you sampled": decode continuation
-            ids = [[t] for t in res[-1]["tokens"]]
-        toks = model.forward(ids, s["seq_ids"], s["dec_lens"])
-        res.append(dict(tokens=toks, logits=logits_log[-1]))
+    for si, (t, lg) in enumerate(zip(base_toks, base_logits)):
+        want = keep != "none" and (keep_steps is None or si in keep_steps)
+        res.append(dict(tokens=t, logits=None if not want else (lg.cpu() if keep == "storage" else lg.float().cpu())))
     torch.save(res, args.out)
     print(f"reference forward: {len(res)} steps -> {args.out}")
+
+    if variants:
+        # the base run's own decisiveness: smallest top-2 gap over all rows
+        gaps = torch.stack([lg.float().topk(2, dim=1).values for lg in base_logits])        # [S, B, 2]
+        gap = (gaps[..., 0] - gaps[..., 1])
+        summary = dict(dtype=dtype_name, steps=len(base_toks), batch=batch,
+                       base=dict(min_top2_gap=float(gap.min()), median_top2_gap=float(gap.median()),
+                                 max_abs_logit=float(max(float(lg.float().abs().max()) for lg in base_logits)),
+                                 default_seq_block_size="model.py:305-324 heuristic"),
+                       variants=[])
+        for var in variants:
+            kw = dict(split=int(var.get("split", 1)), reverse=bool(var.get("reverse", False)))
+            plan["seq_block_size"] = var.get("seq_block_size")
+            f_toks, f_logits = run_script(forced=base_toks, **kw)
+            worst_abs = worst_ulp = 0.0
+            mism, not_near_tie, per_step = [], 0, []
+            for si, (a, b) in enumerate(zip(f_logits, base_logits)):
+                a, b = a.float(), b.float()
+                row_abs = (a - b).abs().amax(dim=1)
+                row_ulp = row_abs / _ulp_of(b.abs().amax(dim=1), dtype_name)
+                worst_abs, worst_ulp = max(worst_abs, float(row_abs.max())), max(worst_ulp, float(row_ulp.max()))
+                per_step.append(dict(step=si, max_abs=float(row_abs.max()), max_ulp_of_row=float(row_ulp.max())))
+                for i, (x, y) in enumerate(zip(f_toks[si], base_toks[si])):
+                    if x != y:
+                        g2 = float(gap[si, i])
+                        mism.append(dict(step=si, seq=i, ref_top2_gap=g2, row_max_abs=float(row_abs[i])))
+                        not_near_tie += int(g2 > 2 * float(row_abs[i]))
+            r_toks, _ = run_script(**kw)
+            first_div = []
+            for i in range(batch):
+                first_div.append(next((s for s in range(len(base_toks)) if r_toks[s][i] != base_toks[s][i]), None))
+            diverged = [d for d in first_div if d is not None]
+            summary["variants"].append(dict(
+                plan=var, teacher_forced=dict(max_abs_dlogit=worst_abs, max_ulp_of_row=worst_ulp,
+                                              token_mismatches=len(mism), tokens_compared=len(base_toks) * batch,
+                                              mismatches_not_on_a_near_tie=not_near_tie, mismatches=mism[:32],
+                                              per_step=per_step),
+                free_running=dict(sequences=batch, identical_to_the_end=batch - len(diverged),
+                                  first_divergence_steps=first_div,
+                                  earliest_divergence_step=min(diverged, default=None))))
+            del f_logits
+        plan["seq_block_size"] = None
+        with open(args.out + ".variants.json", "w", encoding="utf-8") as f:
+            json.dump(summary, f, indent=1)
+        print(f"reference self-distance: {len(variants)} plans -> {args.out}.variants.json")
 
 
 def cmd_ops(args):

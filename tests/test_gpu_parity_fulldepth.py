@@ -1,207 +1,144 @@
-"""Parity at the REAL geometry of BASELINE configs[1] / configs[2] (VERDICT r02 item 1a, SURVEY.md §8c Tier 2):
+"""Parity at the REAL geometry of BASELINE configs[1] / configs[2] (SURVEY.md §8c Tier 2; VERDICT r02 item 1a, r03 item 1a/c/d):
 
 32-layer Llama-3-8B (random-init, full 128 256-token vocabulary), 1024-token prompts, **128 free-running greedy steps**,
 the compiled reference (its own Triton kernels on this MI355X, oracle/ref_triton.py) against the product's default path
 — float16 (the reference's only precision) and bfloat16 (the headline dtype, against the mechanically patched
 float16 -> bfloat16 twin of the reference, oracle/make_ref.py).
 
-For configs[1] (batch 1) the CPU oracle with EXACT scores (oracle/ref_model.py, fp32 accumulation everywhere, the
-reference's rounding points) additionally runs the prompt + 4 teacher-forced decode steps at full depth and arbitrates:
-both implementations' distance to it is reported, and ours must not be the larger one. (Two 16-bit implementations of a
-32-layer random-init network differ by far more than at 2 layers — every layer amplifies the 1-ulp differences of the
-one before — so "how far apart" only means something next to "how far from exact".)
+A random-init 32-layer network amplifies every 1-ulp difference layer after layer and its top-2 logit gap is below one ulp
+on a few rows of every thousand, so two correct 16-bit implementations differ here by tens of ulps and by a few greedy ids.
+"How far apart may they be" is therefore answered by a CONTROL, not by a constant:
 
-Three runs per case:
-  * reference, free-running (feeds itself);
-  * ours, free-running: the token streams must be identical up to each sequence's first divergence, and a divergence is
-    only acceptable where the reference's own top-2 gap in that row is within the PER-ROW logit distance;
-  * ours, teacher-forced with the reference's tokens: logit distance at every one of the 129 steps.
+  * reference vs ITSELF (r03 item 1a): the compiled reference re-runs the same script on the same weights under other legal
+    execution plans — other flash-decoding split widths (model.py:305-324 picks one by heuristic), the batch as two
+    forward() calls of half the sequences (other hipBLASLt kernels) — teacher-forced with its own tokens and free-running.
+    Its self-distance (max |dlogit| in ulps of the row scale, greedy-id mismatches at identical histories, sequences
+    identical to the end) is reported beside ours, and **ours-vs-reference must be within 1.5 x the largest
+    reference-vs-reference' distance** (logits), with no more greedy-id mismatches than 1.5 x the reference's own (+ a
+    floor of 4 ids for the batch-1 case, where the counts are single digits).
+  * every greedy-id difference — ours or the reference's own — must sit on a near-tie: the reference's top-2 gap in that row
+    within twice that row's logit distance.
+  * the CPU oracle with EXACT scores (oracle/ref_model.py) arbitrates at full depth: batch 1 / 1024-token prompt in float16,
+    and batch 32 in float16 AND bfloat16 on 40-token prompts (a 32-layer CPU forward of 32 x 1024 tokens is minutes): both
+    implementations' distance to it, ours must not be the larger one by more than 25 %.
+  * bfloat16 at depth, broken out (r03 item 1d): the default path, the reference's rounding points (`defer_rmsnorm=False`)
+    and the reference's BLAS calls (`fuse_qkv=False, use_skinny_gemm=False`) against the patched reference — reported.
 
 On OUR side the KV pool is 12 288 blocks (24 GB) and filler sequences hold the low block ids, so the test sequences
-live in blocks >= 4096: every pool offset of prefill store, decode store and paged attention is beyond 2^31 elements
-(VERDICT r02 item 2 — a 32-bit wrap anywhere would change the tokens). Block placement is result-invariant, the
-reference side uses its own (low) blocks.
+live in blocks >= 4096: every pool offset of prefill store, decode store and paged attention is beyond 2^31 elements.
 
-The report (first divergence step per sequence, the reference's top-2 gap there, logit distances) goes to
-gpurun_out/parity_fulldepth_<case>_<dtype>.json; the copies under profiles/ are the ones the docs cite.
+Reports: gpurun_out/parity_fulldepth_<case>_<dtype>.json, gpurun_out/parity_fulldepth_arbitration_batch32_<dtype>.json;
+the copies under profiles/ are the ones the docs cite.
 """
 import json
 import os
 import shutil
-import subprocess
-import sys
 
 import pytest
 import torch
 
 from oracle import synth
+from tests import _parity as P
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STAGED = os.path.isfile(os.path.join(ROOT, "oracle", "_ref", "swiftllm", "worker", "model.py"))
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1800),
-              pytest.mark.skipif(not STAGED, reason="oracle/_ref not staged (python -m oracle.make_ref)")]
+              pytest.mark.skipif(not P.STAGED, reason="oracle/_ref not staged (python -m oracle.make_ref)")]
 
 GEN = 128
 PROMPT = 1024
-POOL_BLOCKS = 12288          # 24 GB of KV pool on our side
-HIGH_BLOCK = 4096            # block id from which a pool offset exceeds 2^31 elements (1 MiB = 2^19 elements per block)
 CASES = {"configs1_batch1": 1, "configs2_batch32": 32}
-
-
-def _ulp(x: torch.Tensor, dtype) -> torch.Tensor:
-    mant = 10 if dtype == torch.float16 else 7
-    return torch.exp2(torch.floor(torch.log2(x.abs().clamp(min=2.0 ** -14))) - mant)
+# reference-vs-itself plans; model.py:305-324 picks 64 at batch 1 and 256 at batch 32 for these contexts
+SELF_PLANS = {1: [dict(seq_block_size=128), dict(seq_block_size=512)],
+              32: [dict(seq_block_size=128), dict(seq_block_size=512), dict(split=2)]}
 
 
 @pytest.fixture(scope="module")
-def checkpoints(tmp_path_factory):
+def checkpoint(tmp_path_factory):
     """ONE 32-layer Llama-3-8B checkpoint (float16 values, 16 GB), written once and removed at module teardown. The bfloat16
-    case loads the same file: both sides round the float16 weights to bfloat16 on load (the reference: weight.py:50
+    cases load the same file: both sides round the float16 weights to bfloat16 on load (the reference: weight.py:50
     `.to(item.dtype)`; ours: the per-tensor loader path), to the same bits."""
-    made = {}
-
-    def get(dtype):
-        if "ckpt" not in made:
-            cfg = synth.make_config(**synth.LLAMA3_8B)
-            path = str(tmp_path_factory.mktemp("llama3_8b"))
-            sd = synth.make_state_dict_on_gpu(cfg, seed=2024, dtype=torch.float16)
-            synth.write_model_dir(path, cfg, sd)
-            del sd
-            made["ckpt"] = (cfg, path)
-        return made["ckpt"]
-    yield get
-    for _, path in made.values():
-        shutil.rmtree(path, ignore_errors=True)
-
-
-def _run_reference(tmp_path, cfg, path, dtype, prompts, batch):
-    seq_ids = list(range(batch))
-    script, cur = [dict(input_ids=prompts, seq_ids=seq_ids, dec_lens=[])], [len(p) for p in prompts]
-    for _ in range(GEN):
-        cur = [n + 1 for n in cur]
-        script.append(dict(input_ids=None, seq_ids=seq_ids, dec_lens=list(cur)))
-    num_blocks = batch * (-(-(PROMPT + GEN + 1) // 16) + 1) + 4
-    torch.save(dict(config=cfg, model_path=path, num_blocks=num_blocks, max_len=PROMPT + GEN + 16, steps=script,
-                    dtype=dtype, logits="storage"), tmp_path / "job.pt")
-    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-    env.pop("TRITON_INTERPRET", None)
-    r = subprocess.run([sys.executable, "-m", "oracle.ref_triton", "forward", str(tmp_path / "job.pt"),
-                        str(tmp_path / "ref.pt")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    return torch.load(tmp_path / "ref.pt", weights_only=False)
-
-
-def _our_model(path, dtype, batch):
-    from swiftllm_amd import EngineConfig, LlamaModel
-    model = LlamaModel(EngineConfig(model_path=path, use_dummy=False, block_size=16, gpu_mem_utilization=0.9,
-                                    num_cpu_blocks=0, max_seqs_in_block_table=batch + 8, max_blocks_per_seq=8192,
-                                    max_batch_size=batch, max_tokens_in_batch=batch * (PROMPT + 16), dtype=dtype))
-    model.load_weights()
-    model.init_kvcache_and_swap(POOL_BLOCKS)
-    # filler sequences (ids batch .. batch+k) take the lowest block ids: the test sequences land at >= HIGH_BLOCK
-    need = batch * (-(-(PROMPT + GEN + 1) // 16))
-    spare, sid = POOL_BLOCKS - need - 2, batch
-    while spare > 0:
-        n = min(spare, 8192)
-        model.gpu_block_manager.allocate_blocks_for_seqs([sid], [n * 16])
-        spare -= n
-        sid += 1
-    model.post_layer.logits_tap = []
-    return model
-
-
-def _generate(model, prompts, batch, forced=None, keep_logits=True):
-    seq_ids = list(range(batch))
-    tap = model.post_layer.logits_tap
-    toks, logits = [model.forward(prompts, seq_ids, [])], []
-    if keep_logits:
-        logits.append(tap[-1].cpu())
-    cur = [len(p) for p in prompts]
-    for s in range(GEN):
-        cur = [n + 1 for n in cur]
-        feed = forced[s] if forced is not None else toks[-1]
-        toks.append(model.forward([[t] for t in feed], seq_ids, list(cur)))
-        if keep_logits:
-            logits.append(tap[-1].cpu())
-        del tap[:]
-    blocks = [b for s in seq_ids for b in model.gpu_block_manager.host.seq_blocks[s]]
-    model.free_seqs_resources(seq_ids)
-    return toks, logits, (min(blocks), max(blocks))
+    cfg = synth.make_config(**synth.LLAMA3_8B)
+    path = str(tmp_path_factory.mktemp("llama3_8b"))
+    sd = synth.make_state_dict_on_gpu(cfg, seed=2024, dtype=torch.float16)
+    synth.write_model_dir(path, cfg, sd)
+    del sd
+    yield cfg, path
+    shutil.rmtree(path, ignore_errors=True)
 
 
 @pytest.mark.parametrize("case,dtype", [("configs1_batch1", "float16"), ("configs2_batch32", "float16"),
                                         ("configs2_batch32", "bfloat16")])
-def test_llama3_8b_full_depth_128_free_running_steps_vs_compiled_reference(tmp_path, checkpoints, case, dtype):
+def test_llama3_8b_full_depth_128_free_running_steps_vs_compiled_reference(tmp_path, checkpoint, case, dtype):
     batch = CASES[case]
     tdtype = torch.float16 if dtype == "float16" else torch.bfloat16
-    cfg, path = checkpoints(dtype)
+    cfg, path = checkpoint
     g = torch.Generator().manual_seed(77)
     prompts = [torch.randint(0, cfg["vocab_size"], (PROMPT,), generator=g).tolist() for _ in range(batch)]
 
-    ref = _run_reference(tmp_path, cfg, path, dtype, prompts, batch)
+    ref, ref_self = P.run_reference(tmp_path, cfg, path, dtype, prompts, GEN, variants=SELF_PLANS[batch])
     ref_toks = [r["tokens"] for r in ref]
     ref_logits = [r["logits"] for r in ref]
 
-    model = _our_model(path, dtype, batch)
-    free_toks, free_logits, (blk_lo, blk_hi) = _generate(model, prompts, batch)
-    forced_toks, forced_logits, _ = _generate(model, prompts, batch, forced=ref_toks)
+    model = P.our_model(path, dtype, batch, PROMPT, GEN)
+    free_toks, free_logits, (blk_lo, blk_hi) = P.generate(model, prompts, GEN)
+    forced_toks, forced_logits, _ = P.generate(model, prompts, GEN, forced=ref_toks)
     del model
     torch.cuda.empty_cache()
-    assert blk_lo >= HIGH_BLOCK, (blk_lo, blk_hi)       # every offset of the run was beyond 2^31 elements
+    assert blk_lo >= P.HIGH_BLOCK, (blk_lo, blk_hi)       # every offset of the run was beyond 2^31 elements
 
-    # ---- teacher-forced: logit distance at all 129 steps, per-row near-tie rule for token differences -------------
-    worst_abs = worst_ulp = 0.0
-    forced_mism, bad = [], []
-    per_step = []
-    for s in range(GEN + 1):
-        a, b = forced_logits[s].float(), ref_logits[s].float()
-        d = (a - b).abs()
-        row_abs = d.amax(dim=1)
-        row_ulp = row_abs / _ulp(b.abs().amax(dim=1), tdtype)
-        worst_abs, worst_ulp = max(worst_abs, float(row_abs.max())), max(worst_ulp, float(row_ulp.max()))
-        per_step.append(dict(step=s, max_abs=float(row_abs.max()), max_ulp_of_row=float(row_ulp.max())))
-        for i, (x, y) in enumerate(zip(forced_toks[s], ref_toks[s])):
-            if x != y:
-                top2 = b[i].topk(2).values
-                gap = float(top2[0] - top2[1])
-                forced_mism.append(dict(step=s, seq=i, ref_top2_gap=gap, row_max_abs=float(row_abs[i])))
-                if gap > 2 * float(row_abs[i]):
-                    bad.append(("teacher-forced", s, i, gap, float(row_abs[i])))
+    forced = P.compare_to_reference(forced_toks, forced_logits, ref_toks, ref_logits, tdtype)
     # ---- free-running: identical streams up to each sequence's first divergence ----------------------------------
-    first_div = []
-    for i in range(batch):
-        step = next((s for s in range(GEN + 1) if free_toks[s][i] != ref_toks[s][i]), None)
+    first_div, free_bad = [], []
+    for i, step in enumerate(P.first_divergences(free_toks, ref_toks)):
         if step is None:
             first_div.append(dict(seq=i, step=None))
             continue
         # both sides saw the same history up to `step`: their logits there are comparable
-        b = ref_logits[step][i].float()
+        b = ref_logits[step][i].cuda().float()
         dist = float((free_logits[step][i].float() - b).abs().max())
         top2 = b.topk(2).values
         gap = float(top2[0] - top2[1])
         first_div.append(dict(seq=i, step=step, ref_top2_gap=gap, row_max_abs=dist))
         if gap > 2 * dist:
-            bad.append(("free-running", step, i, gap, dist))
+            free_bad.append((step, i, gap, dist))
     diverged = [d for d in first_div if d["step"] is not None]
+    self_tf = [v["teacher_forced"] for v in ref_self["variants"]]
+    self_ulp = max(t["max_ulp_of_row"] for t in self_tf)
+    self_mism = max(t["token_mismatches"] for t in self_tf)
     report = dict(case=case, dtype=dtype, model="Llama-3-8B dims, 32 layers, vocab 128256, random init", batch=batch,
                   prompt_len=PROMPT, free_running_steps=GEN,
                   reference="compiled reference Triton path" + (" (float16 -> bfloat16 patched)" if dtype == "bfloat16" else ""),
-                  our_kv_pool_blocks=POOL_BLOCKS, our_block_ids=[blk_lo, blk_hi],
+                  our_kv_pool_blocks=P.POOL_BLOCKS, our_block_ids=[blk_lo, blk_hi],
                   our_min_pool_element_offset=blk_lo * 32 * 8 * 16 * 128,
-                  teacher_forced=dict(max_abs_dlogit=worst_abs, max_ulp_of_row=worst_ulp,
-                                      token_mismatches=len(forced_mism), tokens_compared=(GEN + 1) * batch,
-                                      mismatches=forced_mism[:64]),
+                  teacher_forced=forced,
                   free_running=dict(sequences=batch, identical_to_the_end=batch - len(diverged),
                                     first_divergence=first_div,
                                     earliest_divergence_step=min((d["step"] for d in diverged), default=None)),
-                  per_step=per_step, violations=bad)
-    out_dir = os.path.join(ROOT, "gpurun_out")
-    os.makedirs(out_dir, exist_ok=True)
-    with open(os.path.join(out_dir, f"parity_fulldepth_{case}_{dtype}.json"), "w", encoding="utf-8") as f:
-        json.dump(report, f, indent=1)
-    print("\n[full-depth Tier-2]", case, dtype, json.dumps({k: report[k] for k in ("teacher_forced", "our_block_ids")})[:600],
-          "diverged:", len(diverged), "earliest:", report["free_running"]["earliest_divergence_step"])
-    # ---- arbitration by the exact-score CPU oracle at full depth (batch 1 only: a 32-layer CPU forward per step) ----
+                  reference_vs_itself=ref_self,
+                  control=dict(ours_vs_reference_ulp=forced["max_ulp_of_row"], reference_vs_itself_ulp=self_ulp,
+                               ratio=forced["max_ulp_of_row"] / max(self_ulp, 1e-9),
+                               ours_token_mismatches=forced["token_mismatches"], reference_self_token_mismatches=self_mism,
+                               ours_sequences_identical_to_the_end=batch - len(diverged),
+                               reference_self_sequences_identical_to_the_end=min(
+                                   v["free_running"]["identical_to_the_end"] for v in ref_self["variants"])))
+    # ---- bfloat16 at depth, broken out by what differs from the reference's op sequence (r03 item 1d) ------------------
+    if dtype == "bfloat16":
+        breakout = {}
+        for name, opts in (("reference_rounding_points (defer_rmsnorm=False)", dict(tuning=dict(defer_rmsnorm=False))),
+                           ("reference_blas_calls (fuse_qkv=False, use_skinny_gemm=False)",
+                            dict(fuse_qkv=False, use_skinny_gemm=False))):
+            m = P.our_model(path, dtype, batch, PROMPT, GEN, high_blocks=False, **opts)
+            t, lg, _ = P.generate(m, prompts, GEN, forced=ref_toks)
+            del m
+            torch.cuda.empty_cache()
+            c = P.compare_to_reference(t, lg, ref_toks, ref_logits, tdtype)
+            breakout[name] = {k: c[k] for k in ("max_abs_dlogit", "max_ulp_of_row", "token_mismatches",
+                                                "mismatches_not_on_a_near_tie")}
+            del lg
+        report["bf16_breakout_vs_patched_reference"] = breakout
+    P.write_report(f"parity_fulldepth_{case}_{dtype}.json", report)
+    print("\n[full-depth Tier-2]", case, dtype, json.dumps(report["control"]),
+          json.dumps(report.get("bf16_breakout_vs_patched_reference", {})))
+    # ---- arbitration by the exact-score CPU oracle at full depth (batch 1: the real 1024-token prompt) ----------------
     if batch == 1 and dtype == "float16":
         from safetensors.torch import load_file
         from oracle.ref_model import RefLlamaModel
@@ -220,9 +157,9 @@ def test_llama3_8b_full_depth_128_free_running_steps_vs_compiled_reference(tmp_p
             oracle.forward([[ref_toks[s][0]]], [0], [PROMPT + 1 + s])     # teacher-forced like the forced run
             exact.append(oracle.last_logits.clone())
         del oracle, sd
-        ours_d = max(float((forced_logits[s].float() - exact[s]).abs().max()) for s in range(n_dec + 1))
+        ours_d = max(float((forced_logits[s].float().cpu() - exact[s]).abs().max()) for s in range(n_dec + 1))
         ref_d = max(float((ref_logits[s].float() - exact[s]).abs().max()) for s in range(n_dec + 1))
-        scale = float(_ulp(torch.stack(exact).abs().amax(dim=2).max(), tdtype))
+        scale = float(P.ulp(torch.stack(exact).abs().amax(dim=2).max(), tdtype))
         report["exact_oracle_arbitration"] = dict(
             steps=n_dec + 1, ours_vs_exact_max_abs=ours_d, reference_vs_exact_max_abs=ref_d,
             ours_vs_exact_ulp_of_row=ours_d / scale, reference_vs_exact_ulp_of_row=ref_d / scale,
@@ -230,15 +167,80 @@ def test_llama3_8b_full_depth_128_free_running_steps_vs_compiled_reference(tmp_p
                                                for s in range(n_dec + 1)),
             reference_token_mismatches_vs_exact=sum(int(ref_logits[s][0].float().argmax()) != int(exact[s][0].argmax())
                                                     for s in range(n_dec + 1)))
-        with open(os.path.join(out_dir, f"parity_fulldepth_{case}_{dtype}.json"), "w", encoding="utf-8") as f:
-            json.dump(report, f, indent=1)
+        P.write_report(f"parity_fulldepth_{case}_{dtype}.json", report)
         print("[full-depth arbitration by the exact oracle]", json.dumps(report["exact_oracle_arbitration"]))
         assert ours_d <= 1.25 * ref_d, report["exact_oracle_arbitration"]
     # Every token difference sits on a near-tie of the reference (per row: gap <= 2 x that row's logit distance) ...
+    assert forced["mismatches_not_on_a_near_tie"] == 0 and not free_bad, (forced["mismatches"], free_bad)
+    # ... and ours is no farther from the reference than the reference is from itself under another legal plan (x 1.5)
+    assert forced["max_ulp_of_row"] <= 1.5 * self_ulp, report["control"]
+    assert forced["token_mismatches"] <= 1.5 * self_mism + 4, report["control"]
+
+
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_exact_oracle_arbitrates_batch32_at_full_depth(tmp_path, checkpoint, dtype):
+    """r03 item 1c: the exact-score CPU oracle at full depth for BATCH 32, float16 and bfloat16: 32 x 40-token prompts + 3
+    teacher-forced decode steps (the oracle's tokens feed all three parties). Ours must be no farther from exact than the
+    compiled reference is (x 1.25), and wherever ours picks another greedy id than the exact oracle, the oracle's top-2 gap
+    must be within twice that row's distance."""
+    from safetensors.torch import load_file
+    from oracle.ref_model import RefLlamaModel
+    from swiftllm_amd import EngineConfig, LlamaModelConfig
+    batch, plen, n_dec = 32, 40, 3
+    tdtype = torch.float16 if dtype == "float16" else torch.bfloat16
+    cfg, path = checkpoint
+    g = torch.Generator().manual_seed(78)
+    prompts = [torch.randint(0, cfg["vocab_size"], (plen,), generator=g).tolist() for _ in range(batch)]
+    seq_ids = list(range(batch))
+    sd = load_file(os.path.join(path, "model.safetensors"))
+    oracle = RefLlamaModel(LlamaModelConfig(cfg), EngineConfig(
+        model_path="", use_dummy=False, block_size=16, gpu_mem_utilization=0.9, num_cpu_blocks=0,
+        max_seqs_in_block_table=batch, max_blocks_per_seq=8, max_batch_size=batch, max_tokens_in_batch=batch * plen), sd,
+        tdtype, score_dtype="fp32")
+    oracle.init_kvcache_and_swap(batch * 4)
+    exact_toks, exact = [oracle.forward(prompts, seq_ids, [])], [oracle.last_logits.clone()]
+    for s in range(n_dec):
+        exact_toks.append(oracle.forward([[t] for t in exact_toks[-1]], seq_ids, [plen + 1 + s] * batch))
+        exact.append(oracle.last_logits.clone())
+    del oracle, sd
+    # the compiled reference, teacher-forced with the oracle's tokens
+    script = [dict(input_ids=prompts, seq_ids=seq_ids, dec_lens=[])]
+    for s in range(n_dec):
+        script.append(dict(input_ids=[[t] for t in exact_toks[s]], seq_ids=seq_ids, dec_lens=[plen + 1 + s] * batch))
+    import subprocess
+    import sys
+    torch.save(dict(config=cfg, model_path=path, num_blocks=batch * 4 + 4, max_len=plen + 16, steps=script, dtype=dtype,
+                    logits="fp32"), tmp_path / "job.pt")
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    env.pop("TRITON_INTERPRET", None)
+    r = subprocess.run([sys.executable, "-m", "oracle.ref_triton", "forward", str(tmp_path / "job.pt"),
+                        str(tmp_path / "ref.pt")], cwd=P.ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    ref_logits = [x["logits"] for x in torch.load(tmp_path / "ref.pt", weights_only=False)]
+    model = P.our_model(path, dtype, batch, plen, n_dec + 1)
+    toks, logits, (blk_lo, _) = P.generate(model, prompts, n_dec, forced=exact_toks)
+    del model
+    torch.cuda.empty_cache()
+    assert blk_lo >= P.HIGH_BLOCK
+    ours_d = max(float((logits[s].float().cpu() - exact[s]).abs().max()) for s in range(n_dec + 1))
+    ref_d = max(float((ref_logits[s] - exact[s]).abs().max()) for s in range(n_dec + 1))
+    scale = float(P.ulp(torch.stack(exact).abs().amax(dim=2).max(), tdtype))
+    bad, ours_mism, ref_mism = [], 0, 0
+    for s in range(n_dec + 1):
+        ref_mism += int((ref_logits[s].argmax(dim=1) != exact[s].argmax(dim=1)).sum())
+        for i in range(batch):
+            if toks[s][i] != exact_toks[s][i]:
+                ours_mism += 1
+                top2 = exact[s][i].topk(2).values
+                dist = float((logits[s][i].float().cpu() - exact[s][i]).abs().max())
+                if float(top2[0] - top2[1]) > 2 * dist:
+                    bad.append((s, i, float(top2[0] - top2[1]), dist))
+    report = dict(dtype=dtype, batch=batch, prompt_len=plen, steps=n_dec + 1, layers=32,
+                  ours_vs_exact_max_abs=ours_d, reference_vs_exact_max_abs=ref_d,
+                  ours_vs_exact_ulp_of_row=ours_d / scale, reference_vs_exact_ulp_of_row=ref_d / scale,
+                  ours_token_mismatches_vs_exact=ours_mism, reference_token_mismatches_vs_exact=ref_mism,
+                  tokens_compared=batch * (n_dec + 1))
+    P.write_report(f"parity_fulldepth_arbitration_batch32_{dtype}.json", report)
+    print("\n[full-depth arbitration, batch 32]", json.dumps(report))
     assert not bad, bad
-    # ... and the logits stay within the band measured between the two implementations at this depth (r03: 33.5 / 37.9
-    # fp16 ulps of the row scale at batch 1 / 32, 40.3 bf16 ulps against the bf16-patched reference; at 2 layers the same
-    # pair is 7 ulps apart): the reference rounds its decode scores to the storage dtype (paged_attn.py:72-73), its
-    # q/k/v are three hipBLASLt calls where ours is one fused MFMA kernel on packed weights, and 32 random-init layers
-    # amplify every 1-ulp difference. A regression guard, not a precision claim — that is the arbitration above.
-    assert worst_ulp <= 64.0, (worst_ulp, worst_abs)
+    assert ours_d <= 1.25 * ref_d, report

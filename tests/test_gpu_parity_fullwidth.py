@@ -261,6 +261,130 @@ def test_full_width_logits_hold_the_absolute_1e3_bar_when_it_is_meaningful(tmp_p
     assert not failures, failures
 
 
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_piggybacked_mixed_step_at_llama3_8b_width(tmp_path, dtype):
+    """VERDICT r03 item 1e — BASELINE configs[2] is "piggybacked prefill+decode (SARATHI path)": the two-stream mixed forward
+    (reference transformer_layer.py:78-79,101-114) at the shape bench.py times — **4 fresh 1024-token prompts + 28 decoding
+    sequences in ONE forward** at Llama-3-8B width (2 layers) — against the exact-score CPU oracle and the compiled reference.
+    Script: prefill the 28 old sequences (ragged, 150..1087 tokens) -> the MIXED step -> one pure-decode step of all 32 (it
+    reads the K/V the mixed step stored for both kinds of sequence). 4 x 1024 + 28 = 4124 rows: the row-block rule of
+    kernels/linear.py for > 4096-row BLAS calls is on the path.
+    Bars as in test_full_width_forward_matches_oracle: logits within 3 ulps of the row scale of the exact oracle and no
+    farther from it than the reference's own score rounding; greedy ids equal except on the oracle's near-ties; and against
+    the compiled reference: ours no farther from exact than it is (x 1.25 + one ulp), same greedy ids up to its near-ties."""
+    import subprocess
+    import sys
+    from swiftllm_amd import EngineConfig, LlamaModel, LlamaModelConfig
+    tdtype = torch.float16 if dtype == "float16" else torch.bfloat16
+    cfg = synth.make_config(**CFG)
+    sd = synth.make_state_dict(cfg, seed=33, dtype=tdtype)
+    g = torch.Generator().manual_seed(9)
+    old_lens = [150 + (i * 937) % 938 for i in range(28)]
+    old_lens[3], old_lens[17] = 1087, 1024
+    old = [torch.randint(0, cfg["vocab_size"], (n,), generator=g).tolist() for n in old_lens]
+    new = [torch.randint(0, cfg["vocab_size"], (1024,), generator=g).tolist() for _ in range(4)]
+    old_ids, new_ids = list(range(28)), [28, 29, 30, 31]
+    num_blocks = sum(-(-(n + 3) // 16) for n in old_lens) + 4 * 66 + 4
+    kw = dict(use_dummy=False, block_size=16, gpu_mem_utilization=0.9, num_cpu_blocks=0, max_seqs_in_block_table=32,
+              max_blocks_per_seq=72, max_batch_size=32, max_tokens_in_batch=28 * 1100, dtype=dtype)
+
+    def run_script(fwd, logits_of):
+        """the three forwards, teacher-forced by the exact oracle's tokens once they exist"""
+        out = []
+        t0 = fwd(old, old_ids, [])
+        out.append((t0, logits_of()))
+        feed0 = want[0][0] if want else t0
+        t1 = fwd(new + [[t] for t in feed0], new_ids + old_ids, [n + 1 for n in old_lens])
+        out.append((t1, logits_of()))
+        feed1 = want[1][0] if want else t1
+        t2 = fwd([[t] for t in feed1], new_ids + old_ids, [1025] * 4 + [n + 2 for n in old_lens])
+        out.append((t2, logits_of()))
+        return out
+
+    want = []
+    teacher = RefLlamaModel(LlamaModelConfig(cfg), EngineConfig(model_path="", **kw), sd, tdtype, score_dtype="fp32")
+    teacher.init_kvcache_and_swap(num_blocks)
+    want = run_script(teacher.forward, lambda: teacher.last_logits.clone())
+    del teacher
+    noisy = RefLlamaModel(LlamaModelConfig(cfg), EngineConfig(model_path="", **kw), sd, tdtype, score_dtype="ref")
+    noisy.init_kvcache_and_swap(num_blocks)
+    noise = run_script(noisy.forward, lambda: noisy.last_logits.clone())
+    del noisy
+
+    def distance(got):
+        rows = []
+        for s, ((toks, lg), (wt, wl)) in enumerate(zip(got, want)):
+            d = (lg.float().cpu() - wl).abs()
+            row_ulp = _ulp(wl.abs().amax(dim=1, keepdim=True), tdtype)
+            ties_ok = True
+            mism = [i for i, (x, y) in enumerate(zip(toks, wt)) if x != y]
+            for i in mism:
+                top2 = wl[i].topk(2).values
+                ties_ok &= float(top2[0] - top2[1]) <= 2 * float(d[i].max())
+            rows.append(dict(step=("prefill_28", "mixed_4x1024+28", "decode_32")[s], max_abs=float(d.max()),
+                             max_ulp_of_row=float((d / row_ulp).max()), mismatches=len(mism), all_on_near_ties=ties_ok))
+        return rows
+
+    synth.write_model_dir(str(tmp_path / "model"), cfg, sd)
+    report = dict(dtype=dtype, model=CFG, workload="28 ragged prefills -> 4 x 1024-token prompts + 28 decodes in one forward "
+                  "-> 32 decodes", rows_in_mixed_step=4 * 1024 + 28,
+                  noise_floor_ref_scores_vs_exact=distance(noise))
+    noise_ulp = max(r["max_ulp_of_row"] for r in report["noise_floor_ref_scores_vs_exact"])
+    failures = []
+    ours_logits = {}
+    for name, opts in (("default", dict()), ("eager_launches", dict(use_hip_graph=False))):
+        model = LlamaModel(EngineConfig(model_path=str(tmp_path / "model"), **kw, **opts))
+        model.load_weights()
+        model.init_kvcache_and_swap(num_blocks)
+        model.post_layer.logits_tap = []
+        tap = model.post_layer.logits_tap
+        got = run_script(model.forward, lambda: tap[-1].float().cpu())
+        del model
+        torch.cuda.empty_cache()
+        report[name] = rows = distance(got)
+        ours_logits[name] = [lg for _, lg in got]
+        for r in rows:
+            if r["max_ulp_of_row"] > 3.0 or r["max_ulp_of_row"] > max(noise_ulp, 1.0):
+                failures.append(f"{name} {r['step']}: {r['max_ulp_of_row']:.2f} ulp of the row scale from the exact oracle "
+                                f"(the reference's score rounding: {noise_ulp:.2f})")
+            if not r["all_on_near_ties"]:
+                failures.append(f"{name} {r['step']}: greedy id differs from the oracle's away from a near-tie")
+    if STAGED:      # the compiled reference runs the same three forwards, fed the oracle's tokens
+        script = [dict(input_ids=old, seq_ids=old_ids, dec_lens=[]),
+                  dict(input_ids=new + [[t] for t in want[0][0]], seq_ids=new_ids + old_ids, dec_lens=[n + 1 for n in old_lens]),
+                  dict(input_ids=[[t] for t in want[1][0]], seq_ids=new_ids + old_ids,
+                       dec_lens=[1025] * 4 + [n + 2 for n in old_lens])]
+        torch.save(dict(config=cfg, model_path=str(tmp_path / "model"), num_blocks=num_blocks, max_len=1100, steps=script,
+                        dtype=dtype), tmp_path / "job.pt")
+        env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+        env.pop("TRITON_INTERPRET", None)
+        r = subprocess.run([sys.executable, "-m", "oracle.ref_triton", "forward", str(tmp_path / "job.pt"),
+                            str(tmp_path / "ref.pt")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        tri = [x["logits"] for x in torch.load(tmp_path / "ref.pt", weights_only=False)]
+        ref_d = [float((a - wl).abs().max()) for a, (_, wl) in zip(tri, want)]
+        vs = [float((a - b).abs().max()) for a, b in zip(ours_logits["default"], tri)]
+        ours_d = [r["max_abs"] for r in report["default"]]
+        report["compiled_reference"] = dict(reference_vs_oracle_max_abs=ref_d, ours_vs_reference_max_abs=vs)
+        # arbitration: ours is no farther from the exact oracle than the compiled reference is (x 1.25 + one ulp of the
+        # largest logit), and the two pick the same greedy ids except on the reference's own near-ties
+        one_ulp = [float(_ulp(wl.abs().max(), tdtype)) for _, wl in want]
+        for s in range(3):
+            if ours_d[s] > 1.25 * ref_d[s] + one_ulp[s]:
+                failures.append(f"step {s}: ours {ours_d[s]:.3e} from exact vs the compiled reference's {ref_d[s]:.3e}")
+            a, b = ours_logits["default"][s], tri[s]
+            for i in (a.argmax(dim=1) != b.argmax(dim=1)).nonzero().flatten().tolist():
+                top2 = b[i].topk(2).values
+                if float(top2[0] - top2[1]) > 2 * float((a[i] - b[i]).abs().max()):
+                    failures.append(f"step {s} seq {i}: greedy id differs from the compiled reference's away from a near-tie")
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, f"parity_fullwidth_mixed_step_{dtype}.json"), "w", encoding="utf-8") as f:
+        json.dump(report, f, indent=1)
+    print("\n[mixed step at 8B width]", dtype, json.dumps(report)[:1500])
+    assert not failures, failures
+
+
 @pytest.mark.parametrize("name", ["scalar1", "scalar4", "dict"])
 def test_product_rope_tables_match_reference_golden(tmp_path, golden, name):
     """a10: the PRODUCT's device-evaluated cos/sin tables (LlamaModel._init_to_get_rotary), incl. scalar > 1 and

@@ -547,3 +547,36 @@ def test_block_planner_arithmetic_and_fixed_rule_mirror():
             assert (calls or [m]) == P.fixed_rule(m), m
     finally:
         torch.mm = real
+
+
+def test_reference_harness_plans_keep_the_scripts_sequence_order():
+    """oracle/ref_triton.py: planned_step — the reference-vs-itself control runs a step as several forward() calls and / or
+    in reverse order; whatever the plan, tokens and logits must come back in the script's order, prefill sequences must
+    precede decoding ones in every call and every decoding length must travel with its sequence."""
+    import torch
+    from oracle.ref_triton import planned_step
+
+    class Fake:
+        def __init__(self):
+            self.calls = []
+
+        def forward(self, ids, seq_ids, dec_lens):
+            n_pre = len(ids) - len(dec_lens)
+            assert all(len(x) > 1 for x in ids[:n_pre]) and all(len(x) == 1 for x in ids[n_pre:])
+            self.calls.append((list(seq_ids), list(dec_lens)))
+            for sid, dl in zip(seq_ids[n_pre:], dec_lens):
+                assert dl == 100 + sid          # the length that belongs to this sequence
+            log.append(torch.tensor([[float(s), float(x[-1])] for s, x in zip(seq_ids, ids)]))
+            return [10 * s + x[-1] for s, x in zip(seq_ids, ids)]
+
+    ids = [[1, 2, 3], [4, 5], [6], [7], [8]]
+    seq_ids = [40, 41, 0, 1, 2]
+    dec_lens = [100, 101, 102]
+    want_t = [10 * s + x[-1] for s, x in zip(seq_ids, ids)]
+    want_l = torch.tensor([[float(s), float(x[-1])] for s, x in zip(seq_ids, ids)])
+    for split, reverse in ((1, False), (2, False), (1, True), (2, True), (3, False)):
+        log, fake = [], Fake()
+        t, lg = planned_step(fake, log, ids, seq_ids, dec_lens, split, reverse)
+        assert t == want_t and torch.equal(lg, want_l), (split, reverse)
+        assert len(fake.calls) == min(split, 3)
+        assert sorted(s for c in fake.calls for s in c[0]) == sorted(seq_ids)

@@ -375,61 +375,95 @@ def gemm_roofline(model, batch, iters):
                 bytes_per_launch=int(alg_bytes), us_per_launch=round(us, 2), launches=iters)
 
 
-def cpu_baseline(cfg, batch, context, dtype):
-    """The CPU oracle (a port: the reference has no CPU forward) on the host cores: ONE transformer layer of the same
-    architecture at the bench's batch and MEAN TIMED CONTEXT — KV pool filled directly with N(0,1) data, no prompt
-    pass — a few decode steps; the layer cost (attention over the real context included) is timed apart from
-    embedding + lm_head and recombined for the full depth. ~10-30 s including building the random weights. This is the
-    ONLY part of bench.py that touches oracle/."""
+MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: bf16/fp16 dense MFMA ~2.5 PF (measured 2495 TF with 32x32x16)
+
+
+def prefill_flops(cfg, lens):
+    """Arithmetic of one prompt pass as executed: the projections on every token, causal attention (half the S x S
+    products), lm_head on the last token of each sequence only (post_layer.py:18-40)."""
+    L, h, I, V = cfg["num_hidden_layers"], cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"]
+    H = cfg["num_attention_heads"]
+    D = h // H
+    kvd = cfg["num_key_value_heads"] * D
+    gemm = 2 * L * (2 * h * h + 2 * kvd * h + 3 * I * h) * sum(lens) + 2 * len(lens) * V * h
+    attn = L * sum(2 * n * n * D * H for n in lens)
+    return gemm, attn
+
+
+def prefill_attention_roofline(model, lens, iters=24):
+    """The one hand-written COMPUTE-bound kernel of the path — csrc/prefill_attn.hip, varlen causal flash attention — at
+    the prompt pass's shapes, HIP events on the launch stream: causal flops (4 * sum(len^2) * D * H / 2) per launch / mean
+    launch duration against the dense MFMA peak."""
+    import types
+    import torch
+    from swiftllm_amd.worker.kernels.prefill_attn import prefill_attention
+    mc = model.model_config
+    H, KVH, D = mc.num_q_heads, mc.num_kv_heads, mc.head_dim
+    P = sum(lens)
+    dev = model.device
+    q = torch.randn(P, H, D, device=dev, dtype=torch.float32).to(model.dtype)
+    k = torch.randn(P, KVH, D, device=dev, dtype=torch.float32).to(model.dtype)
+    v = torch.randn(P, KVH, D, device=dev, dtype=torch.float32).to(model.dtype)
+    o = torch.empty_like(q)
+    cu = torch.zeros(len(lens) + 1, dtype=torch.int32)
+    cu[1:] = torch.cumsum(torch.tensor(lens, dtype=torch.int32), 0)
+    st = types.SimpleNamespace(num_prefill_seqs=len(lens), max_prefill_len=max(lens), softmax_scale=D ** -0.5,
+                               prefill_seq_start_locs_with_end=cu.to(dev))
+    us = _event_time(lambda i: prefill_attention(q, k, v, o, mc, None, st), iters, 3)
+    flop = sum(2 * n * n * D * H for n in lens)
+    tf = flop / (us * 1e-6) / 1e12
+    return dict(bound="mfma", kernel="swl_prefill_attn_varlen (prefill_attn_kernel: varlen causal GQA flash attention, MFMA 32x32x16)",
+                achieved=round(tf, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / MFMA_PEAK_TFLOPS, 4),
+                flops_per_launch=int(flop), us_per_launch=round(us, 1), launches=iters, traffic=None)
+
+
+def cpu_baseline(cfg, batch, context, dtype, steps=2):
+    """The CPU oracle (a port: the reference has no CPU forward) on the host cores: the FULL-DEPTH decode forward of the same
+    architecture at the bench's batch and MEAN TIMED CONTEXT — all layers timed, nothing extrapolated (r03 timed one layer
+    and multiplied). KV pool filled directly with N(0,1) data, no prompt pass; one untimed warm-up step, then `steps` timed
+    decode steps (~10 s each on a 128-core host). Layer 0's weights are drawn at random and layers 1.. are rolled copies of
+    them (distinct memory — nothing is served from cache that a real checkpoint would stream — without minutes of CPU
+    randn for 8 G parameters). This is the ONLY part of bench.py that touches oracle/."""
     import torch
     from oracle import eager_ops, synth
     from oracle.ref_model import RefLlamaModel
     from swiftllm_amd import EngineConfig, LlamaModelConfig
-    small = dict(cfg, num_hidden_layers=1)
+    L = cfg["num_hidden_layers"]
     tdtype = torch.bfloat16 if dtype == "bfloat16" else torch.float16
-    sd = synth.make_state_dict(small, seed=0, dtype=tdtype)
-    steps = 3
-    blocks_per_seq = (context + steps) // 16 + 2
+    sd = synth.make_state_dict(dict(cfg, num_hidden_layers=1), seed=0, dtype=tdtype)
+    for i in range(1, L):
+        for k in [k for k in sd if k.startswith("model.layers.0.")]:
+            sd[k.replace("model.layers.0.", f"model.layers.{i}.")] = torch.roll(sd[k], shifts=i, dims=0)
+    blocks_per_seq = (context + steps + 1) // 16 + 2
     ec = EngineConfig(model_path="", use_dummy=True, block_size=16, gpu_mem_utilization=0.9,
                       num_cpu_blocks=0, max_seqs_in_block_table=batch, max_blocks_per_seq=blocks_per_seq + 2,
                       max_batch_size=batch, max_tokens_in_batch=batch * 16)
     eager_ops.linear = lambda a, w: torch.nn.functional.linear(a, w)    # native 16-bit CPU GEMM
-    ref = RefLlamaModel(LlamaModelConfig(small), ec, sd, tdtype, dense_decode_attention=True)
+    ref = RefLlamaModel(LlamaModelConfig(cfg), ec, sd, tdtype, dense_decode_attention=True)
     ref.init_kvcache_and_swap(batch * blocks_per_seq)
     g = torch.Generator().manual_seed(1)
-    ref.k_cache.copy_(torch.randn(ref.k_cache.shape, generator=g).to(tdtype))
-    ref.v_cache.copy_(torch.randn(ref.v_cache.shape, generator=g).to(tdtype))
-    layer_s = [0.0]
-    orig_layer = ref._layer
-
-    def timed_layer(*a):
-        t0 = time.perf_counter()
-        r = orig_layer(*a)
-        layer_s[0] += time.perf_counter() - t0
-        return r
-    ref._layer = timed_layer
+    one = torch.randn(ref.k_cache[:, :1].shape, generator=g).to(tdtype)          # one layer's worth, shared by all layers
+    ref.k_cache.copy_(one.expand_as(ref.k_cache))
+    ref.v_cache.copy_(one.flip(0).expand_as(ref.v_cache))
+    del one
     toks = torch.randint(0, cfg["vocab_size"], (batch,), generator=g).tolist()
     first = context - steps // 2
-    total, layers = 0.0, 0.0
+    total = 0.0
     for s in range(-1, steps):      # step -1: untimed warm-up (allocates the blocks, touches the weights)
-        layer_s[0] = 0.0
         t0 = time.perf_counter()
         toks = ref.forward([[t] for t in toks], list(range(batch)), [first + s] * batch)
         if s >= 0:
             total += time.perf_counter() - t0
-            layers += layer_s[0]
-    per_layer = layers / steps
-    rest = (total - layers) / steps
-    full_step = per_layer * cfg["num_hidden_layers"] + rest
-    return dict(value=round(batch / full_step, 3), unit="tokens/s", cores=torch.get_num_threads(), kind="port",
-                sample=(f"oracle/ref_model.py decode step, batch {batch}, contexts {first}..{first + steps - 1} (KV pool "
-                        f"filled directly, attention over the full context included — as one dense softmax per sequence), 1 of "
-                        f"{cfg['num_hidden_layers']} layers timed ({per_layer * 1e3:.1f} ms/layer) + embedding/"
-                        f"lm_head ({rest * 1e3:.1f} ms), recombined for {cfg['num_hidden_layers']} layers; "
-                        f"{steps} steps, native 16-bit CPU GEMM"))
+    step_s = total / steps
+    return dict(value=round(batch / step_s, 3), unit="tokens/s", cores=torch.get_num_threads(), kind="port",
+                extrapolated=False,
+                sample=(f"oracle/ref_model.py decode forward at full depth ({L} layers, all timed), batch {batch}, contexts "
+                        f"{first}..{first + steps - 1} (KV pool filled directly; attention over the full context as one "
+                        f"dense softmax per sequence), {steps} steps of {step_s:.2f} s after one warm-up step, native 16-bit "
+                        f"CPU GEMM on {torch.get_num_threads()} threads"))
 
 
-def reference_triton_leg(batch, first_ctx, steps, warmup):
+def reference_triton_leg(batch, first_ctx, steps, warmup, prompt_len):
     """The reference's own data plane on this GPU (oracle/ref_triton.py: its LlamaModel.forward, its Triton kernels
     compiled by Triton's gfx950 backend, F.linear; fp16 — the only precision the reference has) timed in a child
     process at the SAME batch and the SAME timed contexts as `value`. Runs after this process has released its model
@@ -439,7 +473,8 @@ def reference_triton_leg(batch, first_ctx, steps, warmup):
     if not os.path.isfile(os.path.join(ROOT, "oracle", "_ref", "swiftllm", "worker", "model.py")):
         return None
     cmd = [sys.executable, "-m", "oracle.ref_triton", "bench", "--config", "c2", "--batch", str(batch),
-           "--first-context", str(first_ctx), "--steps", str(steps), "--warmup", str(warmup)]
+           "--first-context", str(first_ctx), "--steps", str(steps), "--warmup", str(warmup),
+           "--prefill-len", str(prompt_len)]
     env = dict(os.environ)
     env.pop("TRITON_INTERPRET", None)
     try:
@@ -447,6 +482,7 @@ def reference_triton_leg(batch, first_ctx, steps, warmup):
         d = json.loads(r.stdout.strip().splitlines()[-1])
         return dict(value=d["decode_tok_s"], unit="tokens/s", ms_per_step=d["ms_per_step"], dtype=d["dtype"],
                     contexts=[d["context_first"], d["context_last"]], steps=d["steps"], warmup=d["warmup"],
+                    prefill_tok_s=d.get("prefill_tok_s"), prefill_ms=d.get("prefill_ms"),
                     path=d["path"], how="child process: " + " ".join(cmd[1:]))
     except Exception as e:     # noqa: BLE001
         print(f"[bench] reference Triton leg failed ({type(e).__name__}: {e})", file=sys.stderr)
@@ -635,12 +671,25 @@ def _run(args):
                    "hip_graph": not args.no_hip_graph, "fuse_qkv": args.fuse_qkv,
                    "skinny_gemm": args.skinny_gemm, "packed_decode_weights": getattr(args, "packed_weights", True),
                    **pool, "decode_graphs_captured": graphs,
-                   "cpu_affinity_cores": len(pinned) if pinned else None},
+                   "cpu_affinity_cores": len(pinned) if pinned else len(os.sched_getaffinity(0)),
+                   "cpu_affinity": dict(dp.last_affinity) if world > 1 else dict(
+                       cores=len(os.sched_getaffinity(0)), how="single rank on this host: not pinned, all allowed cores")},
         "step_roofline": step_roofline(cfg, e, B, mean_ctx, ms_per_step),
     }
     if prefill_units is not None:
         result["prefill_tok_s"] = round(prefill_units / prefill_max_s, 1)
         result["prefill_ms"] = round(prefill_max_s * 1e3, 2)
+        gemm_f, attn_f = prefill_flops(cfg, [S] * B)
+        tf = world * (gemm_f + attn_f) / prefill_max_s / 1e12
+        result["prefill_roofline"] = {
+            "bound": "mfma", "achieved": round(tf / world, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / world / MFMA_PEAK_TFLOPS, 4), "flops_per_pass": int(gemm_f + attn_f),
+            "gemm_share_of_flops": round(gemm_f / (gemm_f + attn_f), 4),
+            "what": "whole prompt forward per GPU: executed flops (projections on every token, causal attention, lm_head on "
+                    "the last tokens) / wall time of the forward",
+            "dominant_kernel": "hipBLASLt Cijk_* MT256x256x64 (F.linear, the reference's own call, kernels/linear.py:3-12): "
+                               "~90 % of the pass — profiles/r03_kernel_trace_configs2.md; the hand-written attention kernel "
+                               "is priced separately in prefill_attention_roofline"}
     # `roofline` = the kernel with the largest share of the step; the other hand-written heavyweight next to it
     attn = attention_roofline(model, run.lens, args.kernel_iters)
     gemm = gemm_roofline(model, B, args.kernel_iters)
@@ -650,6 +699,11 @@ def _run(args):
         result["roofline"] = attn
         if gemm is not None:
             result["roofline_up_gate_gemm"] = gemm
+    if world == 1 and not args.skip_prefill:
+        try:
+            result["prefill_attention_roofline"] = prefill_attention_roofline(model, [S] * B)
+        except Exception as exc:     # noqa: BLE001 — a side measurement must never take the bench line down
+            print(f"[bench] prefill attention roofline failed ({type(exc).__name__}: {exc})", file=sys.stderr)
     if world == 1 and not args.no_extras:
         # the same K steps with hipGraph replay off (one HIP launch per kernel from Python), same contexts
         if not args.no_hip_graph:
@@ -681,7 +735,7 @@ def _run(args):
         result["configs3_llama2_7b_4x16k"] = (side_run_fresh_process(args, label)
                                               or side_run(args, "llama2-7b", 4, 16384 + 32, 24, 4, label))
     if world == 1 and not args.no_extras and not args.no_reference and args.model == "llama3-8b":
-        ref = reference_triton_leg(B, first_ctx, K, Wm)
+        ref = reference_triton_leg(B, first_ctx, K, Wm, S)
         if ref is not None:
             result["reference_triton"] = ref
     if world == 1 and not args.no_cpu_baseline:

@@ -11,6 +11,7 @@ import os
 import socket
 import subprocess
 import sys
+import time
 from typing import List, Sequence, Tuple
 
 import torch
@@ -86,32 +87,51 @@ def spawn_local_ranks(argv: Sequence[str], world_size: int, timeout_s: float = N
             env["HIP_VISIBLE_DEVICES"] = str(visible_devices[r])
         elif not restricted:
             env["HIP_VISIBLE_DEVICES"] = str(r)
-        procs.append(subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else sys.stderr))
+        procs.append(subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else _stderr_fd()))
     worst = 0
+    deadline = None if timeout_s is None else time.monotonic() + timeout_s
+    kill_at = None                      # set once the survivors have been told to terminate
     try:
         pending = list(procs)
         while pending:
             for p in list(pending):
                 try:
-                    rc = p.wait(timeout=0.5)
+                    rc = p.wait(timeout=0.2)
                 except subprocess.TimeoutExpired:
                     continue
                 pending.remove(p)
-                if rc != 0:
+                if rc != 0 and kill_at is None:
                     worst = worst or rc
                     for q in pending:       # a dead rank leaves the others waiting in a barrier for ever
                         q.terminate()
-            if timeout_s is not None:
-                timeout_s -= 0.5 * max(1, len(pending))
-                if timeout_s <= 0 and pending:
-                    for q in pending:
-                        q.terminate()
-                    worst = worst or 124
+                    kill_at = time.monotonic() + TERMINATE_GRACE_S
+            now = time.monotonic()
+            if deadline is not None and now >= deadline and pending and kill_at is None:
+                for q in pending:
+                    q.terminate()
+                worst = worst or 124
+                kill_at = now + TERMINATE_GRACE_S
+            if kill_at is not None and now >= kill_at:
+                for q in pending:           # stuck in a HIP call or ignoring SIGTERM
+                    q.kill()
+                kill_at = float("inf")
     finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()
     return worst
+
+
+TERMINATE_GRACE_S = 10.0
+
+
+def _stderr_fd():
+    """Where the non-zero ranks' stdout goes: this process's stderr as a real file descriptor (sys.stderr may be a
+    wrapper without one under pytest or a notebook)."""
+    try:
+        return sys.stderr.fileno()
+    except (AttributeError, OSError, ValueError):
+        return 2
 
 
 def _parse_cpulist(text: str) -> List[int]:
@@ -147,15 +167,17 @@ def _gpu_numa_nodes() -> List[int]:
     return out
 
 
-def cpus_for_local_rank(local_rank: int, local_world: int, allowed: Sequence[int] = None) -> List[int]:
-    """The host cores replica `local_rank` of `local_world` should run on: the cores of its GPU's NUMA node, split
-    evenly among the replicas that share the node (8 Python processes each feeding one GPU — the
-    host side is the only shared resource of the request-sharded path). Falls back to an even contiguous split of
-    the allowed cores when the topology is not readable."""
+def affinity_plan(local_rank: int, local_world: int, allowed: Sequence[int] = None) -> Tuple[List[int], str]:
+    """(cores, how): the host cores replica `local_rank` of `local_world` should run on — the cores of its GPU's NUMA node,
+    split evenly among the replicas that share the node (8 Python processes each feeding one GPU — the host
+    side is the only shared resource of the request-sharded path) — and, in words, which rule produced them. When the
+    topology is not readable (containers often hide /sys/class/kfd or report numa_node -1) the allowed cores are split
+    evenly and contiguously, so eight ranks never share the same cores."""
     allowed = sorted(allowed if allowed is not None else os.sched_getaffinity(0))
     if local_world <= 1 or not allowed:
-        return list(allowed)
+        return list(allowed), "single replica on this host: all allowed cores"
     nodes = _gpu_numa_nodes()
+    why = "GPU NUMA topology unreadable (/sys/class/kfd)"
     if len(nodes) >= local_world and all(n >= 0 for n in nodes[:local_world]):
         mine = nodes[local_rank]
         peers = [r for r in range(local_world) if nodes[r] == mine]
@@ -166,19 +188,32 @@ def cpus_for_local_rank(local_rank: int, local_world: int, allowed: Sequence[int
             node_cpus = []
         if len(node_cpus) >= len(peers):
             b, e = shard_bounds(len(node_cpus), peers.index(local_rank), len(peers))
-            return node_cpus[b:e]
+            return node_cpus[b:e], f"NUMA node {mine} of this rank's GPU, shared by {len(peers)} replica(s)"
+        why = f"NUMA node {mine} has fewer allowed cores than replicas"
+    elif nodes:
+        why = f"GPU NUMA nodes reported as {nodes[:local_world]}"
     b, e = shard_bounds(len(allowed), local_rank, local_world)
-    return allowed[b:e] or list(allowed)
+    return (allowed[b:e] or list(allowed)), f"even split of the {len(allowed)} allowed cores ({why})"
+
+
+def cpus_for_local_rank(local_rank: int, local_world: int, allowed: Sequence[int] = None) -> List[int]:
+    return affinity_plan(local_rank, local_world, allowed)[0]
+
+
+last_affinity = dict(cores=None, how="pin_to_local_cores() not called")
 
 
 def pin_to_local_cores(local_rank: int, local_world: int) -> List[int]:
-    """Apply cpus_for_local_rank to this process (and cap torch's intra-op threads accordingly)."""
-    cpus = cpus_for_local_rank(local_rank, local_world)
+    """Apply affinity_plan to this process (and cap torch's intra-op threads accordingly). What was done, or why nothing
+    was, is left in `last_affinity` for reports (bench.py: config.cpu_affinity)."""
+    cpus, how = affinity_plan(local_rank, local_world)
     try:
         os.sched_setaffinity(0, cpus)
-    except (OSError, AttributeError):
+    except (OSError, AttributeError) as e:
+        last_affinity.update(cores=None, how=f"sched_setaffinity refused ({type(e).__name__}); wanted: {how}")
         return []
     torch.set_num_threads(max(1, min(torch.get_num_threads(), len(cpus))))
+    last_affinity.update(cores=len(cpus), how=how)
     return cpus
 
 

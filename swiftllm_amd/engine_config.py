@@ -32,7 +32,9 @@ class EngineConfig:
 
     # ---- MI355X additions (all optional) -------------------------------------------------------
     # Storage/compute dtype of weights, activations and the KV pool. The reference hard-codes
-    # float16 (model.py:70,147); bfloat16 is the headline precision on MI355X.
+    # float16 (model.py:70,147); bfloat16 is the headline precision on MI355X. NOTE: float16 keeps the reference's
+    # rounding points everywhere, so the two bfloat16-only decode fast paths below (defer_rmsnorm, tiny_decode_batches)
+    # are off for it: ~1.5 us per layer slower at batch 32, 7 instead of 5 launches per layer at batch <= 2.
     dtype: str = "float16"
     # One [h + 2*KVH*D, h] GEMM instead of three (the reference left this commented out,
     # weight.py:131). fuse_qkv=False + use_skinny_gemm=False reproduces the reference's exact BLAS calls.

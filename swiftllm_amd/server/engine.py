@@ -49,6 +49,8 @@ class Engine:
         self._undelivered: List[Tuple[Request, int, bool]] = []
         self._stop = threading.Event()
         self._model_thread: Optional[threading.Thread] = None
+        # event-loop thread only: requests somebody may still be waiting on (woken with `error` set if the model thread dies)
+        self._live: set = set()
 
     async def _run_on_model_async(self, func, *args, **kwargs):
         return await self.event_loop.run_in_executor(None, functools.partial(func, *args, **kwargs))
@@ -85,6 +87,7 @@ class Engine:
     # ---- request entry points -----------------------------------------------------------------------------
     def _enqueue(self, raw_request: RawRequest) -> Request:
         request = Request(raw_request)
+        self._live.add(request)         # (event-loop thread; leaves in _deliver / on rejection / in _fail_live)
         self.untokenized_raw_requests.append((request, raw_request))
         return request
 
@@ -128,19 +131,29 @@ class Engine:
                 if req.error is None:
                     servable.append(req)
                 else:           # answer at once: waiters wake up with no tokens, streams end
+                    self._live.discard(req)
                     req.finished_event.set()
                     req.output_q.put_nowait(None)
             if servable:
                 self._inbox.put(servable)
             await asyncio.sleep(0.001)
 
-    @staticmethod
-    def _deliver(outputs: List[Tuple[Request, int, bool]]):
+    def _deliver(self, outputs: List[Tuple[Request, int, bool]]):
         """Fan one step's tokens out to the per-request queues and events (event-loop thread)."""
         for req, tok, finished in outputs:
             req.output_q.put_nowait(StepOutput(tok, req))
             if finished:
+                self._live.discard(req)
                 req.finished_event.set()
+
+    def _fail_live(self, why: str):
+        """The model thread is gone: wake every caller still waiting (event-loop thread). `add_request_and_wait` returns
+        with what was generated so far and `request.error` set; streams end."""
+        live, self._live = list(self._live), set()
+        for req in live:
+            req.error = req.error or why
+            req.finished_event.set()
+            req.output_q.put_nowait(None)
 
     # ---- model thread ---------------------------------------------------------------------------------------------
     def _post_undelivered(self):
@@ -239,10 +252,17 @@ class Engine:
         thread.start()
         try:
             await failed
+        except BaseException as exc:        # the model thread died (or we are being cancelled): nobody may wait for ever
+            self._fail_live(f"engine stopped: {type(exc).__name__}: {exc}")
+            raise
         finally:
             self._stop.set()
             self._inbox.put([])     # wake it if it is waiting for arrivals
-            thread.join(10.0)       # (at most the step in flight)
+            # (at most the step in flight) — joined off the event loop: HTTP and the other coroutines keep running
+            try:
+                await asyncio.shield(self.event_loop.run_in_executor(None, thread.join, 10.0))
+            except asyncio.CancelledError:
+                pass
 
     async def start_all_event_loops(self):
         assert self.initialized, "Engine not initialized. Please call `initialize()` before starting the event loop."

@@ -18,7 +18,8 @@ the o_proj / down_proj slabs only do the element-wise part, in a launch that fil
 the per-token 1/rms is applied by the consumer of the normalised activations — the slab-fed attention prologue for the
 qkv projection, the SiLU-gate GEMM's epilogue for the FFN — in fp32, before its one rounding.
 
-Very small decode batches (tiny_decode_batches, <= 4 sequences): the two consumers above disappear altogether — the
+Very small decode batches (tiny_decode_batches; policy limit <= 2 sequences = kernels/linear.py _TINY_POLICY_M, the kernels
+take up to 4; bfloat16 only, as it rides on the deferred norm): the two consumers above disappear altogether — the
 qkv projection and the up/gate projection sum the previous projection's slabs themselves while their first weight
 tiles are in flight (kernels/linear.py: linear_splitk_from_splitk / linear_silu_gate_from_splitk, csrc/gemm_tiny.hip),
 the residual stream ping-pongs between two buffers: 5 launches per layer instead of 7.
@@ -50,7 +51,7 @@ class LlamaTransformerLayer:
         self.layer_id = layer_id
         self.skinny = bool(getattr(engine_config, "use_skinny_gemm", False))
         self._qkv_splits = None     # k-splits the skinny GEMM picks for the fused qkv projection (cached)
-        self._tiny_ok = None        # can this layer run the <= 4-token path (cached)
+        self._tiny_ok = None        # can this layer run the tiny-batch (<= TINY_POLICY_M sequences) path (cached)
 
     def _split_qkv(self, qkv: torch.Tensor):
         cfg = self.model_config
@@ -111,7 +112,7 @@ class LlamaTransformerLayer:
         return self._qkv_splits in (1, 2, 4)
 
     def _tiny_decode_applies(self, st, partials, residual_buf) -> bool:
-        """<= 4 decoding sequences on the deferred-norm fast path, every projection of the layer split over K (so the
+        """<= TINY_POLICY_M (2) decoding sequences on the deferred-norm fast path, every projection of the layer split over K (so the
         NEXT layer receives slabs again) and the two consuming projections able to rebuild their input themselves."""
         cfg, ecfg, w = self.model_config, self.engine_config, self.weight
         if not (getattr(ecfg, "tiny_decode_batches", True) and partials.shape[0] <= TINY_POLICY_M

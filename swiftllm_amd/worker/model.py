@@ -170,7 +170,15 @@ class LlamaModel:
         block_bytes = ecfg.block_size * self.model_config.get_kvslot_size(self.dtype)
         # the two block tables (GPU + CPU manager) are allocated after this point: budget them
         table_bytes = 2 * ecfg.max_seqs_in_block_table * ecfg.max_blocks_per_seq * 4
-        num_blocks = math.floor((usable - peak_memory - table_bytes) / block_bytes)
+        # ... and so is the private memory pool of the decode hipGraphs (captured on first use, AFTER the KV pool took
+        # its share): a max_batch_size decode forward's activations, [B, vocab] logits (+ fp32 argmax candidates) and
+        # split-K scratch. The eager prefill peak above does not contain it.
+        graph_bytes = 0
+        if getattr(ecfg, "use_hip_graph", False):
+            cfg = self.model_config
+            b = ecfg.max_batch_size
+            graph_bytes = (b * cfg.vocab_size * 8 + b * (cfg.hidden_size + cfg.ffn_inter_dim) * 64 + (64 << 20))
+        num_blocks = math.floor((usable - peak_memory - table_bytes - graph_bytes) / block_bytes)
         torch.cuda.empty_cache()
         return max(num_blocks, 0)
 

@@ -549,3 +549,29 @@ def test_router_in_front_of_two_real_replicas_on_one_gpu(tmp_path):
                 p.wait(timeout=20)
             except subprocess.TimeoutExpired:
                 p.kill()
+
+
+def test_waiters_wake_up_when_the_model_thread_dies():
+    """a forward() that raises kills the model thread; callers of add_request_and_wait / add_request_and_stream
+    must not hang — they return with `request.error` set — and start_all_event_loops re-raises the failure."""
+    class Exploding(FakeModel):
+        def forward(self, input_ids, seq_ids, decoding_lens):
+            if decoding_lens:
+                raise RuntimeError("HIP error: boom")
+            return super().forward(input_ids, seq_ids, decoding_lens)
+
+    async def scenario():
+        engine = Engine(_cfg(max_batch_size=3), model=Exploding())
+        await engine.initialize()
+        loops = asyncio.ensure_future(engine.start_all_event_loops())
+        waiter = asyncio.ensure_future(engine.add_request_and_wait(RawRequest("", 4, [1, 2, 3])))
+
+        async def stream():
+            return [o.token_id async for o in engine.add_request_and_stream(RawRequest("", 4, [4, 5]))]
+        streamer = asyncio.ensure_future(stream())
+        req, toks = await asyncio.wait_for(waiter, 20)
+        got = await asyncio.wait_for(streamer, 20)
+        assert req.error and "boom" in req.error and len(toks) < 4 and len(got) < 4
+        with pytest.raises(RuntimeError, match="boom"):
+            await asyncio.wait_for(loops, 20)
+    asyncio.run(scenario())

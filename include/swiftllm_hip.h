@@ -265,6 +265,19 @@ int swl_gemm_packed_mid_choose_splits(int32_t M, int32_t N, int32_t K); /* its c
 int swl_gemm_packed_mid_silu_gate(void *out, const void *x, const void *w_up_gate_packed, int32_t M, int32_t I,
                                   int32_t K, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype,
                                   swl_stream_t stream);
+/* Large decode batches on a packed weight (csrc/gemm_wide.hip): out[M, N] = x . W^T for up to 256 tokens — the projections
+ * of reference kernels/linear.py:3-12 (transformer_layer.py:54-56,117,126,128) at the batch sizes a 264 GB KV pool holds;
+ * every weight fragment feeds ceil(M/32) <= 8 MFMAs, x^T shared by the workgroup through LDS. N % 32 == 0, K % 64 == 0.
+ * waves_per_group: 0 = library's choice, 4 or 8; k_splits: 0 = library's choice, else a power of two <= 16 with
+ * K % (64 * k_splits) == 0; workspace >= k_splits * M * N * 4 bytes when K is split. */
+int swl_gemm_packed_wide(void *out, const void *x, const void *w_packed, void *workspace, size_t workspace_bytes,
+                         int32_t M, int32_t N, int32_t K, int64_t x_row_stride, int64_t out_row_stride,
+                         int32_t waves_per_group, int32_t k_splits, int32_t dtype, swl_stream_t stream);
+size_t swl_gemm_packed_wide_workspace_bytes(int32_t M, int32_t N, int32_t K); /* for the library's own plan */
+/* ... with the SiLU-gate of the FFN (reference kernels/silu_and_mul.py:5-34) in its epilogue: out[M, I] = up * silu(gate) */
+int swl_gemm_packed_wide_silu_gate(void *out, const void *x, const void *w_up_gate_packed, int32_t M, int32_t I,
+                                   int32_t K, int64_t x_row_stride, int64_t out_row_stride, int32_t waves_per_group,
+                                   int32_t dtype, swl_stream_t stream);
 /* ... stopping at the fp32 partial slabs [k_splits][M][N] (k_splits >= 1) for the split-K consumers */
 int swl_gemm_packed_mid_partial(float *slabs, size_t slabs_bytes, const void *x, const void *w_packed, int32_t M,
                                 int32_t N, int32_t K, int64_t x_row_stride, int32_t k_splits, int32_t dtype,

@@ -246,8 +246,10 @@ def cmd_forward(args):
         seq_block_size=N   the flash-decoding split width (model.py:305-324 picks one by heuristic; any power of two >= 64
                            is a legal value of the same kernel, paged_attn.py:35-108) — other partial-softmax merges;
         split=k            the batch as k forward() calls of batch/k sequences each — other GEMM row counts, hence other
-                           hipBLASLt kernels / K-split orders;
-        reverse=True       the sequences in reverse order.
+                           hipBLASLt kernels / K-split orders (split = batch: every request served alone);
+        pad=k              k dummy sequences ride along in every call (for a batch that cannot be split);
+        reverse=True       the sequences in reverse order;
+        max_steps=n        only the first n scripted steps, teacher-forced only (for plans that cost many calls).
     For each variant: the script teacher-forced with the base run's tokens (logit distance and greedy-id mismatches at
     identical histories) and free-running (sequences identical to the end). Summaries go to <out>.variants.json; nothing of
     the reference's arithmetic is touched — only which legal plan it runs."""
@@ -269,7 +271,8 @@ def cmd_forward(args):
         return r
     post_mod.linear = tapped_linear     # the only linear() in post_layer.py is lm_head (:38)
     batch = max(len(s["seq_ids"]) for s in job["steps"])
-    model = _build_model(swiftllm, job["config"], job["model_path"], False, batch, job["max_len"], job["num_blocks"])
+    pad_max = max([int(v.get("pad", 0)) for v in variants] + [0])
+    model = _build_model(swiftllm, job["config"], job["model_path"], False, batch + pad_max, job["max_len"], job["num_blocks"])
     plan = dict(seq_block_size=None)
     inner_forward = model._forward
 
@@ -284,17 +287,38 @@ def cmd_forward(args):
     def run_step(ids, seq_ids, dec_lens, split=1, reverse=False):
         return planned_step(model, logits_log, ids, seq_ids, dec_lens, split, reverse)
 
-    def run_script(forced=None, **kw):
+    all_seqs = sorted({i for s in job["steps"] for i in s["seq_ids"]})
+
+    def run_script(forced=None, split=1, reverse=False, pad=0, max_steps=None):
+        """The scripted steps under a plan. `pad` > 0: that many extra DUMMY sequences ride along in every forward (copies
+        of the step's first prompt with shifted ids, then their own greedy tokens; outputs dropped) — other GEMM row
+        counts for a batch that cannot be split; pure-prefill / pure-decode steps only. `max_steps`: stop early."""
         all_toks, all_logits = [], []
-        for si, s in enumerate(job["steps"]):
+        dummy_ids = [max(all_seqs) + 1 + j for j in range(pad)]
+        dummy_toks, dummy_lens = [], []
+        vocab = job["config"]["vocab_size"]
+        for si, s in enumerate(job["steps"][:max_steps]):
             ids = s["input_ids"]
             if ids is None:     # "feed back what you sampled": decode continuation
                 ids = [[t] for t in (forced[si - 1] if forced is not None else all_toks[-1])]
-            t, lg = run_step(ids, s["seq_ids"], s["dec_lens"], **kw)
+            seq_ids, dec_lens = list(s["seq_ids"]), list(s["dec_lens"])
+            if pad:
+                assert len(dec_lens) in (0, len(seq_ids)), "pad: pure prefill or pure decode steps only"
+                if not dec_lens:
+                    ids = list(ids) + [[(t + 1 + j) % vocab for t in ids[0]] for j in range(pad)]
+                    dummy_lens = [len(ids[0])] * pad
+                else:
+                    dummy_lens = [n + 1 for n in dummy_lens]
+                    ids = list(ids) + [[t] for t in dummy_toks]
+                    dec_lens = dec_lens + dummy_lens
+                seq_ids = seq_ids + dummy_ids
+            t, lg = run_step(ids, seq_ids, dec_lens, split, reverse)
+            if pad:
+                dummy_toks = t[-pad:]
+                t, lg = t[:-pad], lg[:-pad]
             all_toks.append(t)
             all_logits.append(lg)
-        seqs = sorted({i for s in job["steps"] for i in s["seq_ids"]})
-        model.free_seqs_resources(seqs)
+        model.free_seqs_resources(all_seqs + dummy_ids)
         return all_toks, all_logits
 
     base_toks, base_logits = run_script()
@@ -315,7 +339,8 @@ def cmd_forward(args):
                                  default_seq_block_size="model.py:305-324 heuristic"),
                        variants=[])
         for var in variants:
-            kw = dict(split=int(var.get("split", 1)), reverse=bool(var.get("reverse", False)))
+            kw = dict(split=int(var.get("split", 1)), reverse=bool(var.get("reverse", False)), pad=int(var.get("pad", 0)),
+                      max_steps=var.get("max_steps"))
             plan["seq_block_size"] = var.get("seq_block_size")
             f_toks, f_logits = run_script(forced=base_toks, **kw)
             worst_abs = worst_ulp = 0.0
@@ -331,19 +356,20 @@ def cmd_forward(args):
                         g2 = float(gap[si, i])
                         mism.append(dict(step=si, seq=i, ref_top2_gap=g2, row_max_abs=float(row_abs[i])))
                         not_near_tie += int(g2 > 2 * float(row_abs[i]))
-            r_toks, _ = run_script(**kw)
-            first_div = []
-            for i in range(batch):
-                first_div.append(next((s for s in range(len(base_toks)) if r_toks[s][i] != base_toks[s][i]), None))
-            diverged = [d for d in first_div if d is not None]
-            summary["variants"].append(dict(
-                plan=var, teacher_forced=dict(max_abs_dlogit=worst_abs, max_ulp_of_row=worst_ulp,
-                                              token_mismatches=len(mism), tokens_compared=len(base_toks) * batch,
-                                              mismatches_not_on_a_near_tie=not_near_tie, mismatches=mism[:32],
-                                              per_step=per_step),
-                free_running=dict(sequences=batch, identical_to_the_end=batch - len(diverged),
-                                  first_divergence_steps=first_div,
-                                  earliest_divergence_step=min(diverged, default=None))))
+            entry = dict(plan=var, teacher_forced=dict(
+                max_abs_dlogit=worst_abs, max_ulp_of_row=worst_ulp, token_mismatches=len(mism),
+                tokens_compared=len(f_toks) * batch, mismatches_not_on_a_near_tie=not_near_tie, mismatches=mism[:32],
+                per_step=per_step))
+            if kw["max_steps"] is None:     # (a truncated plan is a teacher-forced probe only)
+                r_toks, _ = run_script(**kw)
+                first_div = []
+                for i in range(batch):
+                    first_div.append(next((s for s in range(len(base_toks)) if r_toks[s][i] != base_toks[s][i]), None))
+                diverged = [d for d in first_div if d is not None]
+                entry["free_running"] = dict(sequences=batch, identical_to_the_end=batch - len(diverged),
+                                             first_divergence_steps=first_div,
+                                             earliest_divergence_step=min(diverged, default=None))
+            summary["variants"].append(entry)
             del f_logits
         plan["seq_block_size"] = None
         with open(args.out + ".variants.json", "w", encoding="utf-8") as f:

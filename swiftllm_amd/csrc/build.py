@@ -25,6 +25,7 @@ SOURCES = [
     "swap_blocks.hip",
     "gemm_skinny.hip",
     "gemm_tiny.hip",
+    "gemm_wide.hip",
     "argmax.hip",
 ]
 HEADERS = ["swl_common.h", os.path.join(ROOT, "include", "swiftllm_hip.h")]

@@ -44,7 +44,8 @@ def run_reference(tmp_path, cfg, path, dtype, prompts, gen, variants=None, logit
     summary or None). Logits come back in the storage dtype on the CPU."""
     batch = len(prompts)
     longest = max(len(p) for p in prompts)
-    num_blocks = batch * (-(-(longest + gen + 1) // 16) + 1) + 4
+    pad = max([int(v.get("pad", 0)) for v in (variants or [])] + [0])      # dummy sequences of the widest `pad` plan
+    num_blocks = (batch + pad) * (-(-(longest + gen + 1) // 16) + 1) + 4
     job, out = tmp_path / f"{tag}_job.pt", tmp_path / f"{tag}.pt"
     torch.save(dict(config=cfg, model_path=path, num_blocks=num_blocks, max_len=longest + gen + 16,
                     steps=decode_script(prompts, gen), dtype=dtype, logits="storage", logits_steps=logits_steps,
@@ -138,6 +139,27 @@ def first_divergences(toks, ref_toks):
     """Per sequence: the first step at which a free-running stream leaves the reference's (None = identical to the end)."""
     batch = len(toks[0])
     return [next((s for s in range(len(ref_toks)) if toks[s][i] != ref_toks[s][i]), None) for i in range(batch)]
+
+
+def exact_oracle(cfg, sd, tdtype, batch, max_len):
+    """The CPU oracle with EXACT (fp32) decode scores at full depth, set up to be affordable there: the projection weights
+    are converted to fp32 ONCE (eager_ops.linear computes F.linear(a.float(), w.float()) — for an fp32 `w` the conversion
+    is the identity, so every product and every rounding is what the 16-bit weights give; per-call conversion of 8 G
+    parameters was most of a forward's time), decode attention as one dense softmax per sequence (paged_attention_dense:
+    the same value up to fp32 reassociation, no Python loop per KV block). The embedding stays in the storage dtype."""
+    from oracle.ref_model import RefLlamaModel
+    from swiftllm_amd import EngineConfig, LlamaModelConfig
+    blocks_per_seq = -(-max_len // 16) + 1
+    oracle = RefLlamaModel(LlamaModelConfig(cfg), EngineConfig(
+        model_path="", use_dummy=False, block_size=16, gpu_mem_utilization=0.9, num_cpu_blocks=0,
+        max_seqs_in_block_table=max(2, batch), max_blocks_per_seq=blocks_per_seq + 2, max_batch_size=batch,
+        max_tokens_in_batch=batch * max_len), sd, tdtype, score_dtype="fp32", dense_decode_attention=True)
+    for layer in oracle.layers:
+        for name in ("q_proj", "k_proj", "v_proj", "o_proj", "up_gate_proj", "down_proj"):
+            setattr(layer, name, getattr(layer, name).float())
+    oracle.lm_head = oracle.lm_head.float()
+    oracle.init_kvcache_and_swap(batch * blocks_per_seq + 2)
+    return oracle
 
 
 def write_report(name: str, report: dict) -> str:

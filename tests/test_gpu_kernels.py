@@ -783,6 +783,89 @@ def test_gemm_packed_mid_silu_gate_equals_two_ops(dtype, M, I, Kd):
     assert torch.equal(fused, two[:, :I])
 
 
+# ---- large decode batches: 64 < M <= 256 tokens on packed weights (csrc/gemm_wide.hip) -------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [65, 100, 128, 129, 192, 193, 256, 40])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (6144, 4096), (4096, 14336), (32, 64), (160, 256), (96, 384), (448, 1024),
+                                 (2080, 832)])
+def test_gemm_packed_wide_vs_fp32_reference(dtype, M, N, K):
+    """Large-batch GEMM on packed weights (up to 8 token blocks per weight fragment, x^T shared through LDS): one rounding
+    of an fp32-accumulated product for the library's plan and for forced workgroup widths / K splits; ragged workgroups,
+    token counts that are not multiples of 32, K-chunks shorter than the weight ring. At one K split it carries the bits
+    of the medium-batch kernel (same MFMA order)."""
+    from swiftllm_amd import _hip
+    g = gen(N + K + M)
+    x = torch.randn(M, K, generator=g).to(dtype).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dtype).cuda()
+    ref = x.float() @ w.float().T
+    eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    code = _hip.dtype_code(dtype)
+    wp = torch.empty_like(w)
+    _hip.call("swl_gemm_pack_weight", wp.data_ptr(), w.data_ptr(), N, K, code, _hip.stream())
+    ws = torch.empty(16 * M * N, dtype=torch.float32, device="cuda")
+    mid = None
+    if M <= 128 and K % 128 == 0:
+        mid = torch.empty(M, N, dtype=dtype, device="cuda")
+        _hip.call("swl_gemm_packed_mid", mid.data_ptr(), x.data_ptr(), wp.data_ptr(), 0, 0, M, N, K, K, N, 1, code,
+                  _hip.stream())
+    for nwv in (0, 4, 8):
+        for ks in (0, 1, 2, 4, 8):
+            if ks and K % (64 * ks):
+                continue
+            out = torch.full((M, N), float("nan"), dtype=dtype, device="cuda")
+            _hip.call("swl_gemm_packed_wide", out.data_ptr(), x.data_ptr(), wp.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                      M, N, K, K, N, nwv, ks, code, _hip.stream())
+            assert ((out.float() - ref).abs() <= eps * ref.abs() + 1e-3 * eps * (K ** 0.5)).all(), (nwv, ks)
+            if ks == 1 and mid is not None:
+                assert torch.equal(out, mid), nwv
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [65, 128, 160, 192, 200, 256])
+def test_gemm_packed_wide_up_gate_shape(dtype, M):
+    """The widest projection of a decode layer (Llama-3-8B up/gate: 28672 x 4096) through the plain wide kernel, one
+    M per token-block count 3..8."""
+    from swiftllm_amd import _hip
+    N, K = 28672, 4096
+    g = gen(M)
+    x = torch.randn(M, K, generator=g).to(dtype).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.03).to(dtype).cuda()
+    ref = x.float() @ w.float().T
+    eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    code = _hip.dtype_code(dtype)
+    wp = torch.empty_like(w)
+    _hip.call("swl_gemm_pack_weight", wp.data_ptr(), w.data_ptr(), N, K, code, _hip.stream())
+    for nwv in (0, 8):
+        out = torch.full((M, N), float("nan"), dtype=dtype, device="cuda")
+        _hip.call("swl_gemm_packed_wide", out.data_ptr(), x.data_ptr(), wp.data_ptr(), 0, 0, M, N, K, K, N, nwv, 1, code,
+                  _hip.stream())
+        assert ((out.float() - ref).abs() <= eps * ref.abs() + 1e-3 * eps * (K ** 0.5)).all(), nwv
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,I,Kd", [(256, 14336, 4096), (128, 14336, 4096), (192, 11008, 4096), (65, 256, 128), (100, 96, 384),
+                                    (200, 160, 1280), (129, 96, 1152), (40, 64, 64)])
+def test_gemm_packed_wide_silu_gate_equals_two_ops(dtype, M, I, Kd):
+    """Large-batch SiLU-gate GEMM == large-batch GEMM (one k-split) followed by silu_and_mul, bit for bit, for both
+    workgroup widths (two exchange rounds of MT/2 token blocks through the x buffers)."""
+    from swiftllm_amd import _hip
+    g = gen(M + I)
+    x = torch.randn(M, Kd, generator=g).to(dtype).cuda()
+    w = (torch.randn(2 * I, Kd, generator=g) * 0.03).to(dtype).cuda()
+    code = _hip.dtype_code(dtype)
+    wp = torch.empty_like(w)
+    _hip.call("swl_gemm_pack_weight", wp.data_ptr(), w.data_ptr(), 2 * I, Kd, code, _hip.stream())
+    two = torch.empty(M, 2 * I, dtype=dtype, device="cuda")
+    _hip.call("swl_gemm_packed_wide", two.data_ptr(), x.data_ptr(), wp.data_ptr(), 0, 0, M, 2 * I, Kd, Kd, 2 * I, 0, 1, code,
+              _hip.stream())
+    K().silu_and_mul_inplace(two)
+    for nwv in (0, 4, 8):
+        fused = torch.full((M, I), float("nan"), dtype=dtype, device="cuda")
+        _hip.call("swl_gemm_packed_wide_silu_gate", fused.data_ptr(), x.data_ptr(), wp.data_ptr(), M, I, Kd, Kd, I, nwv, code,
+                  _hip.stream())
+        assert torch.equal(fused, two[:, :I]), nwv
+
+
 # ---- deferred RMSNorm (decode fast path) ---------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,hidden", [(32, 4096), (1, 4096), (7, 1024), (5, 8192)])

@@ -63,7 +63,7 @@ def test_greedy_ids_bit_exact_for_128_free_running_steps_on_the_decisive_checkpo
 
     model = P.our_model(path, dtype, BATCH, 1024, GEN)
     toks, logits, (blk_lo, blk_hi) = P.generate(model, prompts, GEN, logits_steps=LOGIT_STEPS)      # FREE-running
-    graphs = len(getattr(model, "_graphs", {}) or {})
+    graphs = len(getattr(model, "_decode_graphs", {}) or {})
     del model
     torch.cuda.empty_cache()
     assert blk_lo >= P.HIGH_BLOCK, (blk_lo, blk_hi)

@@ -14,13 +14,14 @@ on a few rows of every thousand, so two correct 16-bit implementations differ he
     forward() calls of half the sequences (other hipBLASLt kernels) — teacher-forced with its own tokens and free-running.
     Its self-distance (max |dlogit| in ulps of the row scale, greedy-id mismatches at identical histories, sequences
     identical to the end) is reported beside ours, and **ours-vs-reference must be within 1.5 x the largest
-    reference-vs-reference' distance** (logits), with no more greedy-id mismatches than 1.5 x the reference's own (+ a
+    reference-vs-reference' distance** (logits), with a greedy-id mismatch rate of at most 1.5 x the reference's own (+ a
     floor of 4 ids for the batch-1 case, where the counts are single digits).
   * every greedy-id difference — ours or the reference's own — must sit on a near-tie: the reference's top-2 gap in that row
     within twice that row's logit distance.
   * the CPU oracle with EXACT scores (oracle/ref_model.py) arbitrates at full depth: batch 1 / 1024-token prompt in float16,
-    and batch 32 in float16 AND bfloat16 on 40-token prompts (a 32-layer CPU forward of 32 x 1024 tokens is minutes): both
-    implementations' distance to it, ours must not be the larger one by more than 25 %.
+    and batch 32 in bfloat16 on short prompts (a 32-layer CPU forward of 32 x 1024 tokens is minutes; float16 at batch 32
+    was run once: profiles/r04_parity_fulldepth_arbitration_batch32_float16.json): both implementations' distance to it,
+    ours must not be the larger one by more than 25 %.
   * bfloat16 at depth, broken out (r03 item 1d): the default path, the reference's rounding points (`defer_rmsnorm=False`)
     and the reference's BLAS calls (`fuse_qkv=False, use_skinny_gemm=False`) against the patched reference — reported.
 
@@ -47,8 +48,12 @@ GEN = 128
 PROMPT = 1024
 CASES = {"configs1_batch1": 1, "configs2_batch32": 32}
 # reference-vs-itself plans; model.py:305-324 picks 64 at batch 1 and 256 at batch 32 for these contexts
-SELF_PLANS = {1: [dict(seq_block_size=128), dict(seq_block_size=512)],
-              32: [dict(seq_block_size=128), dict(seq_block_size=512), dict(split=2)]}
+# ... and, so that the control perturbs the projections too (ours differs from the reference in EVERY operator, a split width
+# only in the decode-attention merges): every request served alone (32 calls of batch 1 per step — other hipBLASLt
+# kernels for every GEMM; teacher-forced over the prompt pass + 24 steps, 800 calls), or three dummy sequences riding
+# along with the batch-1 request.
+SELF_PLANS = {1: [dict(seq_block_size=128), dict(seq_block_size=512), dict(pad=3)],
+              32: [dict(seq_block_size=128), dict(seq_block_size=512), dict(split=32, max_steps=25)]}
 
 
 @pytest.fixture(scope="module")
@@ -103,7 +108,8 @@ def test_llama3_8b_full_depth_128_free_running_steps_vs_compiled_reference(tmp_p
     diverged = [d for d in first_div if d["step"] is not None]
     self_tf = [v["teacher_forced"] for v in ref_self["variants"]]
     self_ulp = max(t["max_ulp_of_row"] for t in self_tf)
-    self_mism = max(t["token_mismatches"] for t in self_tf)
+    self_rate = max(t["token_mismatches"] / t["tokens_compared"] for t in self_tf)       # (plans differ in length)
+    ours_rate = forced["token_mismatches"] / forced["tokens_compared"]
     report = dict(case=case, dtype=dtype, model="Llama-3-8B dims, 32 layers, vocab 128256, random init", batch=batch,
                   prompt_len=PROMPT, free_running_steps=GEN,
                   reference="compiled reference Triton path" + (" (float16 -> bfloat16 patched)" if dtype == "bfloat16" else ""),
@@ -116,10 +122,14 @@ def test_llama3_8b_full_depth_128_free_running_steps_vs_compiled_reference(tmp_p
                   reference_vs_itself=ref_self,
                   control=dict(ours_vs_reference_ulp=forced["max_ulp_of_row"], reference_vs_itself_ulp=self_ulp,
                                ratio=forced["max_ulp_of_row"] / max(self_ulp, 1e-9),
-                               ours_token_mismatches=forced["token_mismatches"], reference_self_token_mismatches=self_mism,
+                               ours_token_mismatch_rate=ours_rate, reference_self_token_mismatch_rate=self_rate,
+                               by_plan=[dict(plan=v["plan"], ulp=v["teacher_forced"]["max_ulp_of_row"],
+                                             mismatch_rate=v["teacher_forced"]["token_mismatches"] / v["teacher_forced"]["tokens_compared"])
+                                        for v in ref_self["variants"]],
                                ours_sequences_identical_to_the_end=batch - len(diverged),
                                reference_self_sequences_identical_to_the_end=min(
-                                   v["free_running"]["identical_to_the_end"] for v in ref_self["variants"])))
+                                   v["free_running"]["identical_to_the_end"] for v in ref_self["variants"]
+                                   if "free_running" in v)))
     # ---- bfloat16 at depth, broken out by what differs from the reference's op sequence (r03 item 1d) ------------------
     if dtype == "bfloat16":
         breakout = {}
@@ -141,22 +151,17 @@ def test_llama3_8b_full_depth_128_free_running_steps_vs_compiled_reference(tmp_p
     # ---- arbitration by the exact-score CPU oracle at full depth (batch 1: the real 1024-token prompt) ----------------
     if batch == 1 and dtype == "float16":
         from safetensors.torch import load_file
-        from oracle.ref_model import RefLlamaModel
-        from swiftllm_amd import EngineConfig, LlamaModelConfig
         n_dec = 4
         sd = load_file(os.path.join(path, "model.safetensors"))
-        oracle = RefLlamaModel(LlamaModelConfig(cfg), EngineConfig(
-            model_path="", use_dummy=False, block_size=16, gpu_mem_utilization=0.9, num_cpu_blocks=0,
-            max_seqs_in_block_table=2, max_blocks_per_seq=80, max_batch_size=1, max_tokens_in_batch=PROMPT + 16), sd,
-            tdtype, score_dtype="fp32")
-        oracle.init_kvcache_and_swap(80)
+        oracle = P.exact_oracle(cfg, sd, tdtype, 1, PROMPT + 16)
+        del sd
         exact = []
         oracle.forward(prompts, [0], [])
         exact.append(oracle.last_logits.clone())
         for s in range(n_dec):
             oracle.forward([[ref_toks[s][0]]], [0], [PROMPT + 1 + s])     # teacher-forced like the forced run
             exact.append(oracle.last_logits.clone())
-        del oracle, sd
+        del oracle
         ours_d = max(float((forced_logits[s].float().cpu() - exact[s]).abs().max()) for s in range(n_dec + 1))
         ref_d = max(float((ref_logits[s].float() - exact[s]).abs().max()) for s in range(n_dec + 1))
         scale = float(P.ulp(torch.stack(exact).abs().amax(dim=2).max(), tdtype))
@@ -174,35 +179,32 @@ def test_llama3_8b_full_depth_128_free_running_steps_vs_compiled_reference(tmp_p
     assert forced["mismatches_not_on_a_near_tie"] == 0 and not free_bad, (forced["mismatches"], free_bad)
     # ... and ours is no farther from the reference than the reference is from itself under another legal plan (x 1.5)
     assert forced["max_ulp_of_row"] <= 1.5 * self_ulp, report["control"]
-    assert forced["token_mismatches"] <= 1.5 * self_mism + 4, report["control"]
+    assert ours_rate <= 1.5 * self_rate + 4 / forced["tokens_compared"], report["control"]
 
 
-@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+@pytest.mark.parametrize("dtype", ["bfloat16"])
 def test_exact_oracle_arbitrates_batch32_at_full_depth(tmp_path, checkpoint, dtype):
-    """r03 item 1c: the exact-score CPU oracle at full depth for BATCH 32, float16 and bfloat16: 32 x 40-token prompts + 3
+    """r03 item 1c: the exact-score CPU oracle at full depth for BATCH 32 in the headline dtype: 32 x 24-token prompts + 2
     teacher-forced decode steps (the oracle's tokens feed all three parties). Ours must be no farther from exact than the
-    compiled reference is (x 1.25), and wherever ours picks another greedy id than the exact oracle, the oracle's top-2 gap
-    must be within twice that row's distance."""
+    compiled (bfloat16-patched) reference is (x 1.25), and wherever ours picks another greedy id than the exact oracle, the
+    oracle's top-2 gap must be within twice that row's distance. (float16 at batch 32 ran once in r04 with 40-token prompts
+    + 3 steps — profiles/r04_parity_fulldepth_arbitration_batch32_float16.json: ours 11.75 ulps from exact, the reference
+    20.4 — and stays out of the suite for its 150 s; float16 at batch 1 / 1024-token prompt is arbitrated above.)"""
     from safetensors.torch import load_file
-    from oracle.ref_model import RefLlamaModel
-    from swiftllm_amd import EngineConfig, LlamaModelConfig
-    batch, plen, n_dec = 32, 40, 3
+    batch, plen, n_dec = 32, 24, 2
     tdtype = torch.float16 if dtype == "float16" else torch.bfloat16
     cfg, path = checkpoint
     g = torch.Generator().manual_seed(78)
     prompts = [torch.randint(0, cfg["vocab_size"], (plen,), generator=g).tolist() for _ in range(batch)]
     seq_ids = list(range(batch))
     sd = load_file(os.path.join(path, "model.safetensors"))
-    oracle = RefLlamaModel(LlamaModelConfig(cfg), EngineConfig(
-        model_path="", use_dummy=False, block_size=16, gpu_mem_utilization=0.9, num_cpu_blocks=0,
-        max_seqs_in_block_table=batch, max_blocks_per_seq=8, max_batch_size=batch, max_tokens_in_batch=batch * plen), sd,
-        tdtype, score_dtype="fp32")
-    oracle.init_kvcache_and_swap(batch * 4)
+    oracle = P.exact_oracle(cfg, sd, tdtype, batch, plen + 16)
+    del sd
     exact_toks, exact = [oracle.forward(prompts, seq_ids, [])], [oracle.last_logits.clone()]
     for s in range(n_dec):
         exact_toks.append(oracle.forward([[t] for t in exact_toks[-1]], seq_ids, [plen + 1 + s] * batch))
         exact.append(oracle.last_logits.clone())
-    del oracle, sd
+    del oracle
     # the compiled reference, teacher-forced with the oracle's tokens
     script = [dict(input_ids=prompts, seq_ids=seq_ids, dec_lens=[])]
     for s in range(n_dec):

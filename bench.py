@@ -734,6 +734,22 @@ def _run(args):
         label = "BASELINE.json configs[3]: Llama-2-7B dims, batch 4, 16k context"
         result["configs3_llama2_7b_4x16k"] = (side_run_fresh_process(args, label)
                                               or side_run(args, "llama2-7b", 4, 16384 + 32, 24, 4, label))
+    if world == 1 and not args.no_extras and args.model == "llama3-8b":
+        # the batch sizes the 264 GB pool is sized for: decode-only at 1024-in / mid-generation contexts, one model for both
+        try:
+            need = 256 * (-(-(S + GEN + 64) // 16) + 1) + 8
+            big_args = argparse.Namespace(**dict(vars(args), kv_blocks=need + 1024, kv_placement="bottom"))  # (no profile pass)
+            big = build_model(big_args, ensure_positions(model_config_dict("llama3-8b"), S + GEN + 64), need, 256,
+                              S + GEN + 64, not args.no_hip_graph)
+            for nb in (128, 256):
+                result[f"decode_batch{nb}"] = side_run(
+                    args, "llama3-8b", nb, S + GEN // 2, 24, 6,
+                    f"llama3-8b decode-only, batch {nb} at context ~{S + GEN // 2} (projections: swl_gemm_packed_wide, "
+                    f"csrc/gemm_wide.hip)", model=big)
+            del big
+            torch.cuda.empty_cache()
+        except Exception as exc:     # noqa: BLE001 — a side measurement must never take the bench line down
+            print(f"[bench] large-batch side runs failed ({type(exc).__name__}: {exc})", file=sys.stderr)
     if world == 1 and not args.no_extras and not args.no_reference and args.model == "llama3-8b":
         ref = reference_triton_leg(B, first_ctx, K, Wm, S)
         if ref is not None:

@@ -164,7 +164,7 @@ int swl_paged_attn_phase2(void *o, const float *mid_o, const float *mid_lse,
  * in-repo equivalent prefill_attn.py:9-139 (_fwd_prefill_attention / prefill_attention).
  * q[P, H, D], k/v[P, KVH, D] are the FRESH projections (the paged pool is not read), cu_seqlens is
  * prefill_seq_start_locs_with_end (int32 [Bp+1]); o[P, H, D]. MFMA 32x32x16, fp32 softmax.
- * D in {32, 64, 128}. */
+ * D in {32, 64, 128}; all four tensors 16-byte aligned with token strides that are multiples of 8 elements. */
 int swl_prefill_attn_varlen(void *o, const void *q, const void *k, const void *v,
                             const int32_t *cu_seqlens, int32_t num_prefill_seqs,
                             int32_t max_prefill_len, int32_t num_q_heads, int32_t num_kv_heads,

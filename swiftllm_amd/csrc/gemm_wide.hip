@@ -52,7 +52,9 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_packed_wide_kernel(
     constexpr int RPP = NT / 8;                  // rows per staging pass (8 chunks per row)
     constexpr int kXTile = MT * 32 * kWT;
     constexpr int HW = NWV / 2;
-    constexpr int kWD = XL >= 8 ? 3 : 4;         // W ring depth in tiles (3 where the x staging registers need the room)
+    // x prefetch distance in steps: 2 where two register sets fit beside the accumulators, else 1; W ring depth in tiles
+    constexpr int XD = (MT >= 8 || (NWV == 4 && MT >= 6)) ? 1 : 2;
+    constexpr int kWD = (XD == 1 && XL >= 8) ? 3 : 4;
     static_assert(MT * 256 % NT == 0, "x tile must split evenly over the workgroup");
     __shared__ __attribute__((aligned(16))) T xs[2 * kXTile];
 
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_packed_wide_kernel(
     const int l32 = lane & 31, hf = lane >> 5;
     const int swz = (l32 >> 1) & 7;
 
-    vec8_t<T> wr[kWD][4], xr[XL];
+    vec8_t<T> wr[kWD][4], xr[XD][XL];
     float16_t acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = float16_t{};
@@ -88,14 +90,14 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_packed_wide_kernel(
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                             \
             wr[slot][i_] = load8_nt(wsrc + (static_cast<int64_t>(tile) * 4 + i_) * 512);              \
     }
-#define SWL_W_ISSUE_X(tile)                                                                           \
+#define SWL_W_ISSUE_X(set, tile)                                                                      \
     {                                                                                                \
-        _Pragma("unroll") for (int q_ = 0; q_ < XL; ++q_) xr[q_] = load8(xb + xoff[q_] + (tile) * kWT); \
+        _Pragma("unroll") for (int q_ = 0; q_ < XL; ++q_) xr[set][q_] = load8(xb + xoff[q_] + (tile) * kWT); \
     }
-#define SWL_W_STAGE_X(buf)                                                                            \
+#define SWL_W_STAGE_X(set, buf)                                                                       \
     {                                                                                                \
         _Pragma("unroll") for (int q_ = 0; q_ < XL; ++q_)                                            \
-            *reinterpret_cast<vec8_t<T> *>(xs + (buf) * kXTile + xs_wr0 + q_ * RPP * kWT) = xr[q_];  \
+            *reinterpret_cast<vec8_t<T> *>(xs + (buf) * kXTile + xs_wr0 + q_ * RPP * kWT) = xr[set][q_]; \
     }
 #define SWL_W_PROCESS(slot, buf)                                                                      \
     {                                                                                                \
@@ -108,34 +110,39 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_packed_wide_kernel(
             }                                                                                        \
         }                                                                                            \
     }
-    // x one tile ahead, requested BEFORE that step's W request (loads return in order: staging it at the end of the
-    // step waits for nothing younger than itself); W kWD-1 tiles ahead
+    // Tile t is multiplied in step t. Its x tile was requested in step t-2 (an L2 round trip under load is longer than
+    // the 16-32 MFMAs of one step: r04 measured the one-step distance at 3.4 TB/s on the up/gate shape), sits in register
+    // set t&1 and is written to LDS buffer t&1 at the end of step t-1; W tile t was requested kWD-1 steps ahead. Requests
+    // return in order: x(t+2) is requested BEFORE W(t+kWD-1), so staging x(t+1) at the end of step t waits for nothing
+    // younger than the loads of step t-1.
+    constexpr int U = kWD % 2 == 0 ? kWD : 2 * kWD;     // unroll: ring slot and register set are compile-time
 #pragma unroll
     for (int d = 0; d < kWD - 1; ++d)
         if (d < nkt) SWL_W_ISSUE_W(d, d);
-    SWL_W_ISSUE_X(0);
-    SWL_W_STAGE_X(0);
+    SWL_W_ISSUE_X(0, 0);
+    SWL_W_STAGE_X(0, 0);
+    if (XD == 2 && nkt > 1) SWL_W_ISSUE_X(1 % XD, 1);
     __syncthreads();
     int kt = 0;
-    for (; kt + 2 * kWD - 1 <= nkt; kt += kWD) {
+    for (; kt + U + (kWD > XD + 1 ? kWD - 1 : XD) <= nkt; kt += U) {
 #pragma unroll
-        for (int d = 0; d < kWD; ++d) {
-            SWL_W_ISSUE_X(kt + d + 1);
+        for (int d = 0; d < U; ++d) {
+            SWL_W_ISSUE_X((d + XD) % XD, kt + d + XD);
             SWL_W_ISSUE_W((d + kWD - 1) % kWD, kt + d + kWD - 1);
-            SWL_W_PROCESS(d, (kt + d) & 1);
-            SWL_W_STAGE_X((kt + d + 1) & 1);
+            SWL_W_PROCESS(d % kWD, d & 1);
+            SWL_W_STAGE_X((d + 1) % XD, (d + 1) & 1);
             __syncthreads();
         }
     }
-    const int rem = nkt - kt;
+    const int rem = nkt - kt;       // (kt is a multiple of U, hence even: set / buffer parity below is t & 1)
 #pragma unroll
-    for (int t = 0; t < 2 * kWD - 2; ++t) {
+    for (int t = 0; t < U + (kWD > XD + 1 ? kWD - 1 : XD) - 1; ++t) {
         if (t < rem) {
-            if (t + 1 < rem) SWL_W_ISSUE_X(kt + t + 1);
+            if (t + XD < rem) SWL_W_ISSUE_X((t + XD) % XD, kt + t + XD);
             if (t + kWD - 1 < rem) SWL_W_ISSUE_W((t + kWD - 1) % kWD, kt + t + kWD - 1);
-            SWL_W_PROCESS(t % kWD, (kt + t) & 1);
+            SWL_W_PROCESS(t % kWD, t & 1);
             if (t + 1 < rem) {
-                SWL_W_STAGE_X((kt + t + 1) & 1);
+                SWL_W_STAGE_X((t + 1) % XD, (t + 1) & 1);
                 __syncthreads();
             }
         }
@@ -229,9 +236,12 @@ static WidePlan gemm_wide_plan(int M, int N, int K, int forced_nwv, int forced_k
     p.nwv = forced_nwv ? forced_nwv : ((tiles + 7) / 8 >= 224 ? 8 : 4);
     if (M > 192) p.nwv = 8;     // 8 token blocks + a 4-wave workgroup's staging registers do not fit 256 VGPRs
     const int wgs = (tiles + p.nwv - 1) / p.nwv;
+    // split K until ~2 workgroups per CU (4-wave groups) / ~1.5 (8-wave groups) exist, a split staying >= 4 K-tiles long
+    // and the slabs (2 * ks * M * N * 4 bytes written + read) below ~1.3x the weight bytes (measured optimum on MI355X,
+    // profiles/r04_gemm_wide_micro.jsonl: down_proj ks = 16, o_proj / qkv ks = 8 at M = 96..256)
     int ks = 1;
-    while (ks < 16 && wgs * ks * 2 <= 320 && K % (kWT * ks * 2) == 0 && K / (ks * 2) >= 4 * kWT &&
-           static_cast<int64_t>(ks) * 2 * M * 8 <= static_cast<int64_t>(K) * 2)
+    while (ks < 16 && wgs * ks * 2 <= (p.nwv == 4 ? 640 : 384) && K % (kWT * ks * 2) == 0 && K / (ks * 2) >= 4 * kWT &&
+           static_cast<int64_t>(ks) * 2 * M * 3 <= static_cast<int64_t>(K))
         ks *= 2;
     p.ks = forced_ks ? forced_ks : ks;
     return p;

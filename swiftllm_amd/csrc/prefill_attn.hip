@@ -19,6 +19,8 @@
 //     so no cross-lane shuffle is needed); the per-row rescale factor is lane-local for O^T too;
 //   * the next K/V tile is fetched from HBM/L2 into registers while the current one is consumed
 //     and written to LDS after the barrier (issue-early / write-late staging);
+//   * epilogue: the wave's 32 x D output tile goes through LDS (the dead K/V tiles) and is stored as whole 256-byte rows,
+//     16 bytes per lane (r04; r01-r03 stored 8-byte pieces of 32 rows a token pitch apart per instruction);
 //   * 1-D grid decoded XCD-aware: all Q blocks and the G q-heads of one (sequence, kv-head) land on
 //     one XCD so their shared K/V stays in that XCD's L2; long (late) Q blocks are issued first.
 // Numerics as the reference: fp32 scores * (scale*log2e), exp2, P rounded to the storage dtype for
@@ -68,8 +70,9 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(PrefillParams p) {
     constexpr int CPR = D / 8;           // 16-byte chunks per row
     constexpr int RPP = 256 / CPR;       // rows staged per pass
     constexpr int NPASS = kBK / RPP;     // passes per tile
-    __shared__ __attribute__((aligned(16))) T Ks[kBK * KRS];
-    __shared__ __attribute__((aligned(16))) T Vs[kBK * VRS];
+    __shared__ __attribute__((aligned(16))) T smem[kBK * KRS + kBK * VRS];   // K tile, V tile; the O tiles of the epilogue
+    T *const Ks = smem;
+    T *const Vs = smem + kBK * KRS;
 
     // ---- XCD-aware decode of the 1-D grid ------------------------------------------------------
     const int G = p.H / p.KVH;
@@ -280,19 +283,34 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(PrefillParams p) {
     mfma_results_ready<8>(ot[DT - 1]);
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    if (qrow < len) {
-        T *op = static_cast<T *>(p.o) + (static_cast<int64_t>(start) + qrow) * p.o_tok_stride +
-                static_cast<int64_t>(head) * D + 4 * hf;
+    // O[qrow][d] = O^T[d][qrow] / l, written as WHOLE ROWS: a lane holds 4 consecutive d of ONE row per register quad, so a
+    // direct store instruction touches 32 rows a token pitch apart with 2 x 8 bytes each — 16 such instructions per lane,
+    // the store-issue-bound tail the in-box guide prices at ~4 us per workgroup (T21). The wave's 32 x D tile goes through
+    // LDS instead (the K/V tiles are dead: one barrier, the waves leave the loop together) and comes back row-major,
+    // 16 bytes per lane, 16 lanes = one 256-byte row: 8 full-line stores per lane at D = 128.
+    constexpr int ORS = D + 8;                       // O row pitch in LDS (elements)
+    static_assert(4 * 32 * ORS <= kBK * KRS + kBK * VRS, "the four waves' O tiles must fit the K/V tiles' LDS");
+    __syncthreads();                                 // every wave is done with the last K/V tile
+    T *ow = smem + wave * 32 * ORS;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                typedef T vec4 __attribute__((ext_vector_type(4)));
-                vec4 ov;
+        for (int r4 = 0; r4 < 4; ++r4) {
+            typedef T vec4 __attribute__((ext_vector_type(4)));
+            vec4 ov;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ov[e] = to_t<T>(ot[dt][4 * r4 + e] * inv);
-                *reinterpret_cast<vec4 *>(op + dt * 32 + 8 * r4) = ov;
-            }
+            for (int e = 0; e < 4; ++e) ov[e] = to_t<T>(ot[dt][4 * r4 + e] * inv);
+            *reinterpret_cast<vec4 *>(ow + l32 * ORS + dt * 32 + 8 * r4 + 4 * hf) = ov;
+        }
+    // (wave-private tile: LDS operations of one wave complete in order, no barrier needed)
+    constexpr int RPI = 64 / CPR;                    // rows per store instruction
+    T *obase = static_cast<T *>(p.o) + static_cast<int64_t>(start) * p.o_tok_stride + static_cast<int64_t>(head) * D;
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+        const int row = i * RPI + lane / CPR, ch = lane % CPR;
+        const vec8_t<T> v = *reinterpret_cast<const vec8_t<T> *>(ow + row * ORS + ch * 8);
+        if (q0w + row < len)
+            store8(obase + static_cast<int64_t>(q0w + row) * p.o_tok_stride + ch * 8, v);
     }
 }
 
@@ -311,10 +329,9 @@ extern "C" int swl_prefill_attn_varlen(void *o, const void *q, const void *k, co
     if (num_q_heads <= 0 || num_kv_heads <= 0 || num_q_heads % num_kv_heads != 0)
         return SWL_ERR_BAD_ARG;
     if (!(head_dim == 32 || head_dim == 64 || head_dim == 128)) return SWL_ERR_UNSUPPORTED;
-    if ((q_tok_stride & 7) || (k_tok_stride & 7) || (v_tok_stride & 7) || (o_tok_stride & 3))
+    if ((q_tok_stride & 7) || (k_tok_stride & 7) || (v_tok_stride & 7) || (o_tok_stride & 7))
         return SWL_ERR_BAD_ARG;
-    if (!swl::aligned16(q) || !swl::aligned16(k) || !swl::aligned16(v) ||
-        (reinterpret_cast<uintptr_t>(o) & 7u))
+    if (!swl::aligned16(q) || !swl::aligned16(k) || !swl::aligned16(v) || !swl::aligned16(o))    // (o: 16-byte row stores)
         return SWL_ERR_BAD_ARG;
     swl::PrefillParams p;
     p.o = o;

@@ -110,8 +110,40 @@ def _mid_ok(a: torch.Tensor, w: torch.Tensor) -> bool:
             and (m <= 64 or k >= 2 * n))
 
 
+_WIDE_MAX_M = 256
+
+
+def _wide_ok(a: torch.Tensor, w: torch.Tensor) -> bool:
+    """Large decode batches (64 < M <= 256) on a packed weight: swl_gemm_packed_wide (csrc/gemm_wide.hip) — up to 8 blocks
+    of 32 tokens share every weight fragment, x^T shared by the workgroup through LDS. Which projections it serves is a
+    measured policy (`_wide_wins`, tools/gemm_wide_micro.py against hipBLASLt on MI355X)."""
+    m = a.shape[0] if a.dim() == 2 else 0
+    if not (64 < m <= _WIDE_MAX_M) or _packed_of(w) is None:
+        return False
+    n, k = w.shape
+    return (a.is_cuda and a.dtype == w.dtype and a.stride(1) == 1 and a.stride(0) % 8 == 0 and k % 64 == 0 and n % 32 == 0
+            and m * _row_stride(a) < (1 << 31) and _wide_wins(m, n, k))
+
+
+def _wide_wins(m: int, n: int, k: int) -> bool:
+    """Where the wide kernel beats hipBLASLt (profiles/r04_gemm_wide_micro.jsonl, Llama-3-8B widths, bf16, MI355X): the
+    down projection (K >= 2N) at every M — 38-59 us against 63-104 — and nothing else yet: qkv / o are within 10 % of the
+    library either way, the up/gate projection is 15-40 % behind it."""
+    return k >= 2 * n
+
+
 def linear(a: torch.Tensor, w: torch.Tensor, skinny: bool = False) -> torch.Tensor:
     """a[T, in] @ w[out, in]^T -> [T, out] (fp32 accumulation, one rounding)."""
+    if skinny and _wide_ok(a, w):
+        m, k = a.shape
+        n = w.shape[0]
+        out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+        need = _hip.load().swl_gemm_packed_wide_workspace_bytes(m, n, k)
+        ws = _workspace(a.device, need) if need else None
+        _hip.call("swl_gemm_packed_wide", _hip.ptr(out), _hip.ptr(a), _hip.ptr(_packed_of(w)), _hip.ptr(ws),
+                  ws.numel() * 4 if ws is not None else 0, m, n, k, _row_stride(a), n, 0, 0, _hip.dtype_code(a.dtype),
+                  _hip.stream())
+        return out
     if skinny and _mid_ok(a, w):
         m, k = a.shape
         n = w.shape[0]
@@ -220,6 +252,13 @@ def linear_silu_gate(a: torch.Tensor, w_up_gate: torch.Tensor, row_scale=None):
         _hip.call("swl_gemm_skinny_packed_silu_gate_rs", _hip.ptr(out), _hip.ptr(a), _hip.ptr(_packed_of(w_up_gate)),
                   _hip.ptr(row_scale.ssq), row_scale.parts, row_scale.eps, m, inter, k, _row_stride(a), inter,
                   _hip.dtype_code(a.dtype), _hip.stream())
+        return out
+    if _wide_ok(a, w_up_gate) and w_up_gate.shape[0] % 64 == 0:        # large batch, packed weight
+        m, k = a.shape
+        inter = w_up_gate.shape[0] // 2
+        out = torch.empty((m, inter), dtype=a.dtype, device=a.device)
+        _hip.call("swl_gemm_packed_wide_silu_gate", _hip.ptr(out), _hip.ptr(a), _hip.ptr(_packed_of(w_up_gate)), m, inter, k,
+                  _row_stride(a), inter, 0, _hip.dtype_code(a.dtype), _hip.stream())
         return out
     if _mid_ok(a, w_up_gate) and a.shape[0] <= 64 and w_up_gate.shape[0] % 64 == 0:   # medium batch, packed weight
         m, k = a.shape

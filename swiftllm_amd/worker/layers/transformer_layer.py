@@ -163,6 +163,7 @@ class LlamaTransformerLayer:
         fused_rope_store = (pure_decode and not st.ignore_kvcache and st.position_indices is not None
                             and getattr(ecfg, "fuse_rope_kvstore", False))
         fast = self.skinny and pure_decode and getattr(ecfg, "fuse_splitk_consumers", True)
+        qkv = None
         if (fast and fused_rope_store and w.qkv_proj is not None and getattr(ecfg, "fuse_rope_into_attention", True)
                 and cfg.head_dim in (32, 64, 128)):
             # fused qkv slabs -> (rotary + KV store + paged attention) in one launch
@@ -173,7 +174,8 @@ class LlamaTransformerLayer:
                 return self._forward_after_attention(input_embds, residual_buf, fast)
         assert row_scale is None, "deferred RMSNorm reached a path that cannot apply it"
         if fast and fused_rope_store and w.qkv_proj is not None:
-            qkv = linear_splitk(input_embds, w.qkv_proj)
+            if qkv is None:     # (else: the projection above came back as a plain tensor — batches beyond the slab
+                qkv = linear_splitk(input_embds, w.qkv_proj)    # kernels; r03 computed it a second time here)
             if isinstance(qkv, SplitKPartials):
                 q, k, v = rotary_embedding_and_store_kvcache_decode_from_splitk(
                     qkv, k_cache, v_cache, block_table, cfg, ecfg, st, self.layer_id)

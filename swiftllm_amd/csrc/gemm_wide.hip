@@ -226,23 +226,19 @@ struct WidePlan {
     int ks;     // K splits (fp32 slabs when > 1)
 };
 
-// Workgroup width and K-split for (M, N, K). Wide projections (>= 256 workgroups of 128 rows... the FFN up/gate, lm_head)
-// take 8-wave workgroups when those alone fill the chip, else 4-wave ones; narrow ones (o / qkv / down: N <= 8192) take
-// 4-wave workgroups and split K until ~256 workgroups exist, as long as a split stays >= 4 K-tiles long and the slabs
-// (written once, read once: 2 * ks * M * N * 4 bytes) cost less than the weight bytes N * K * e.
+// Workgroup width and K-split for (M, N, K), from the sweep on MI355X (profiles/r04c_gemm_wide_micro.jsonl, Llama-3-8B
+// widths, bf16, M = 96..256): 4-wave workgroups (two per CU) up to 192 tokens — except the long-K down projection beyond 128
+// tokens — and 8-wave ones above; K split into the largest power of two that keeps a chunk >= 16 K-tiles (4-wave) / 8
+// K-tiles (8-wave) long and the launch at <= 256 workgroups: o / qkv 4 chunks, down 8 at M <= 128; 8 / 8 / 16 with 8 waves.
 static WidePlan gemm_wide_plan(int M, int N, int K, int forced_nwv, int forced_ks) {
     WidePlan p;
     const int tiles = N / 32;
-    p.nwv = forced_nwv ? forced_nwv : ((tiles + 7) / 8 >= 224 ? 8 : 4);
+    p.nwv = forced_nwv ? forced_nwv : ((K >= 2 * N && M > 128) ? 8 : 4);
     if (M > 192) p.nwv = 8;     // 8 token blocks + a 4-wave workgroup's staging registers do not fit 256 VGPRs
     const int wgs = (tiles + p.nwv - 1) / p.nwv;
-    // split K until ~2 workgroups per CU (4-wave groups) / ~1.5 (8-wave groups) exist, a split staying >= 4 K-tiles long
-    // and the slabs (2 * ks * M * N * 4 bytes written + read) below ~1.3x the weight bytes (measured optimum on MI355X,
-    // profiles/r04_gemm_wide_micro.jsonl: down_proj ks = 16, o_proj / qkv ks = 8 at M = 96..256)
+    const int min_chunk = (p.nwv == 4 ? 16 : 8) * kWT;
     int ks = 1;
-    while (ks < 16 && wgs * ks * 2 <= (p.nwv == 4 ? 640 : 384) && K % (kWT * ks * 2) == 0 && K / (ks * 2) >= 4 * kWT &&
-           static_cast<int64_t>(ks) * 2 * M * 3 <= static_cast<int64_t>(K))
-        ks *= 2;
+    while (ks < 16 && wgs * ks * 2 <= 256 && K % (kWT * ks * 2) == 0 && K / (ks * 2) >= min_chunk) ks *= 2;
     p.ks = forced_ks ? forced_ks : ks;
     return p;
 }
@@ -317,7 +313,7 @@ extern "C" int swl_gemm_packed_wide(void *out, const void *x, const void *w_pack
 
 /* out[M, I] = up * silu(gate) of x . [up ; gate]^T for up to 256 tokens on a packed weight (the large-batch twin of
  * swl_gemm_skinny_packed_silu_gate; same rounding points as linear + silu_and_mul). I % 32 == 0, K % 64 == 0.
- * waves_per_group: 0 = library's choice (8), 4 or 8. */
+ * waves_per_group: 0 = library's choice (4 up to 192 tokens, 8 above), 4 or 8. */
 extern "C" int swl_gemm_packed_wide_silu_gate(void *out, const void *x, const void *w_up_gate_packed, int32_t M,
                                               int32_t I, int32_t K, int64_t x_row_stride, int64_t out_row_stride,
                                               int32_t waves_per_group, int32_t dtype, swl_stream_t stream) {
@@ -330,7 +326,7 @@ extern "C" int swl_gemm_packed_wide_silu_gate(void *out, const void *x, const vo
     if (!swl::aligned16(x) || !swl::aligned16(w_up_gate_packed) || (reinterpret_cast<uintptr_t>(out) & 7u))
         return SWL_ERR_BAD_ARG;
     if (!(waves_per_group == 0 || waves_per_group == 4 || waves_per_group == 8)) return SWL_ERR_BAD_ARG;
-    const int nwv = M > 192 ? 8 : (waves_per_group ? waves_per_group : 8);
+    const int nwv = M > 192 ? 8 : (waves_per_group ? waves_per_group : 4);
     const int hw = nwv / 2;
     const int mt = (M + 31) / 32;
     const dim3 grid((I / 32 + hw - 1) / hw, 1);

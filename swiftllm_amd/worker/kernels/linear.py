@@ -125,11 +125,27 @@ def _wide_ok(a: torch.Tensor, w: torch.Tensor) -> bool:
             and m * _row_stride(a) < (1 << 31) and _wide_wins(m, n, k))
 
 
+def _wide_silu_ok(a: torch.Tensor, w: torch.Tensor) -> bool:
+    m = a.shape[0] if a.dim() == 2 else 0
+    if not (64 < m <= _WIDE_MAX_M) or _packed_of(w) is None or w.shape[0] % 64:
+        return False
+    return (a.is_cuda and a.dtype == w.dtype and a.stride(1) == 1 and a.stride(0) % 8 == 0 and w.shape[1] % 64 == 0
+            and m * _row_stride(a) < (1 << 31) and _wide_silu_wins(m))
+
+
 def _wide_wins(m: int, n: int, k: int) -> bool:
-    """Where the wide kernel beats hipBLASLt (profiles/r04_gemm_wide_micro.jsonl, Llama-3-8B widths, bf16, MI355X): the
-    down projection (K >= 2N) at every M — 38-59 us against 63-104 — and nothing else yet: qkv / o are within 10 % of the
-    library either way, the up/gate projection is 15-40 % behind it."""
-    return k >= 2 * n
+    """Where the wide kernel beats (or ties) hipBLASLt — profiles/r04c_gemm_wide_micro.jsonl, Llama-3-8B widths, bf16,
+    MI355X, us ours / library: the down projection (K >= 2N) at every M (M = 96: 33 / 63, 128: 34 / 75, 192: 47 / 102,
+    256: 60 / 63); the narrow projections (qkv, o: N <= 8192) up to 192 tokens (128: 24.7 / 26.3 and 21.3 / 22.2; 192:
+    32.9 / 33.9 and 26.3 / 28.4 — at 256 the library's o_proj is 21 against 36). The plain up/gate projection only ties
+    (53.3 / 54.0 at 128) and loses beyond; its SiLU-gate form is decided in `_wide_silu_wins`."""
+    return k >= 2 * n or (n <= 8192 and m <= 192)
+
+
+def _wide_silu_wins(m: int) -> bool:
+    """up/gate projection + SiLU-gate in one launch against the library GEMM + silu_and_mul: 53.5 / 63.3 us at 128 tokens,
+    60.0 / 62.5 at 96; 88 / 73 at 192 (six token blocks per fragment leave too few waves per CU): up to 128 tokens."""
+    return m <= 128
 
 
 def linear(a: torch.Tensor, w: torch.Tensor, skinny: bool = False) -> torch.Tensor:
@@ -253,7 +269,7 @@ def linear_silu_gate(a: torch.Tensor, w_up_gate: torch.Tensor, row_scale=None):
                   _hip.ptr(row_scale.ssq), row_scale.parts, row_scale.eps, m, inter, k, _row_stride(a), inter,
                   _hip.dtype_code(a.dtype), _hip.stream())
         return out
-    if _wide_ok(a, w_up_gate) and w_up_gate.shape[0] % 64 == 0:        # large batch, packed weight
+    if _wide_silu_ok(a, w_up_gate):        # large batch, packed weight
         m, k = a.shape
         inter = w_up_gate.shape[0] // 2
         out = torch.empty((m, inter), dtype=a.dtype, device=a.device)

@@ -12,7 +12,7 @@ on a few rows of every thousand, so two correct 16-bit implementations differ he
   * reference vs ITSELF (r03 item 1a): the compiled reference re-runs the same script on the same weights under other legal
     execution plans, teacher-forced with its own tokens and free-running; its self-distance (max |dlogit| in ulps of the
     row scale, greedy-id mismatch rate at identical histories, sequences identical to the end) is reported beside ours.
-    MEASURED (r04, profiles/r04_parity_fulldepth_*): the only plan change that moves the reference's bits at all is the
+    MEASURED (r04, profiles/r04b_parity_fulldepth_*): the only plan change that moves the reference's bits at all is the
     flash-decoding split width (model.py:305-324 picks one by heuristic) — serving every request alone (32 calls per step)
     or padding the batch changes nothing beyond the split width the heuristic then picks, i.e. its hipBLASLt GEMMs are
     bit-invariant to the row count — and that ONE-operator perturbation (other fp32 merge orders of the partial softmaxes:
@@ -32,7 +32,9 @@ on a few rows of every thousand, so two correct 16-bit implementations differ he
     was run once: profiles/r04_parity_fulldepth_arbitration_batch32_float16.json): both implementations' distance to it,
     ours must not be the larger one by more than 25 %.
   * bfloat16 at depth, broken out (r03 item 1d): the default path, the reference's rounding points (`defer_rmsnorm=False`)
-    and the reference's BLAS calls (`fuse_qkv=False, use_skinny_gemm=False`) against the patched reference — reported.
+    and the reference's BLAS calls (`fuse_qkv=False, use_skinny_gemm=False`) against the patched reference — a report, run
+    with SWIFTLLM_PARITY_FULL_CONTROL=1 (r04: 39.5 / 42.5 / 40.7 ulps, 25.8 / 26.9 / 26.9 % of ids — neither deviation is
+    what separates ours from the patched reference: profiles/r04b_parity_fulldepth_configs2_batch32_bfloat16.json).
 
 On OUR side the KV pool is 12 288 blocks (24 GB) and filler sequences hold the low block ids, so the test sequences
 live in blocks >= 4096: every pool offset of prefill store, decode store and paged attention is beyond 2^31 elements.
@@ -56,15 +58,18 @@ pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1800),
 GEN = 128
 PROMPT = 1024
 CASES = {"configs1_batch1": 1, "configs2_batch32": 32}
-# reference-vs-itself plans; model.py:305-324 picks 64 at batch 1 and 256 at batch 32 for these contexts
-# ... and, so that the control perturbs the projections too (ours differs from the reference in EVERY operator, a split width
-# only in the decode-attention merges): every request served alone (32 calls of batch 1 per step — other hipBLASLt
-# kernels for every GEMM; teacher-forced over the prompt pass + 24 steps, 800 calls), or three dummy sequences riding
-# along with the batch-1 request.
+# reference-vs-itself plans in the suite: the two other split widths (model.py:305-324 picks 64 at batch 1 and 256 at batch 32
+# for these contexts). r04 also ran `dict(split=32, max_steps=25)` (every request served alone: 800 calls) and `dict(pad=3)`
+# (three dummy sequences beside the batch-1 request) — profiles/r04b_parity_fulldepth_*.json: the single-request plan moves
+# the logits by 10.3-12.0 ulps, i.e. no more than the split width it implies, and padding by exactly 0: the reference's
+# hipBLASLt GEMMs are bit-invariant to the row count. They stay out of the suite for their run time; set
+# SWIFTLLM_PARITY_FULL_CONTROL=1 to run them (and the bfloat16 break-out below) again.
+FULL_CONTROL = os.environ.get("SWIFTLLM_PARITY_FULL_CONTROL") == "1"
 # operator sites per layer at which ours rounds differently from the reference (module docstring)
 SITES = {"float16": 5, "bfloat16": 7}
-SELF_PLANS = {1: [dict(seq_block_size=128), dict(seq_block_size=512), dict(pad=3)],
-              32: [dict(seq_block_size=128), dict(seq_block_size=512), dict(split=32, max_steps=25)]}
+SELF_PLANS = {1: [dict(seq_block_size=128), dict(seq_block_size=512)] + ([dict(pad=3)] if FULL_CONTROL else []),
+              32: [dict(seq_block_size=128), dict(seq_block_size=512)]
+              + ([dict(split=32, max_steps=25)] if FULL_CONTROL else [])}
 
 
 @pytest.fixture(scope="module")
@@ -143,7 +148,7 @@ def test_llama3_8b_full_depth_128_free_running_steps_vs_compiled_reference(tmp_p
                                    v["free_running"]["identical_to_the_end"] for v in ref_self["variants"]
                                    if "free_running" in v)))
     # ---- bfloat16 at depth, broken out by what differs from the reference's op sequence (r03 item 1d) ------------------
-    if dtype == "bfloat16":
+    if dtype == "bfloat16" and FULL_CONTROL:
         breakout = {}
         for name, opts in (("reference_rounding_points (defer_rmsnorm=False)", dict(tuning=dict(defer_rmsnorm=False))),
                            ("reference_blas_calls (fuse_qkv=False, use_skinny_gemm=False)",

@@ -327,7 +327,7 @@ def test_piggybacked_mixed_step_at_llama3_8b_width(tmp_path, dtype):
                   "-> 32 decodes", rows_in_mixed_step=4 * 1024 + 28)
     failures = []
     ours_logits = {}
-    for name, opts in (("default", dict()), ("eager_launches", dict(use_hip_graph=False))):
+    for name, opts in (("default", dict()),):       # (r04b also ran eager launches: bit-identical distances)
         model = LlamaModel(EngineConfig(model_path=str(tmp_path / "model"), **kw, **opts))
         model.load_weights()
         model.init_kvcache_and_swap(num_blocks)

@@ -274,6 +274,11 @@ int swl_gemm_packed_wide(void *out, const void *x, const void *w_packed, void *w
                          int32_t M, int32_t N, int32_t K, int64_t x_row_stride, int64_t out_row_stride,
                          int32_t waves_per_group, int32_t k_splits, int32_t dtype, swl_stream_t stream);
 size_t swl_gemm_packed_wide_workspace_bytes(int32_t M, int32_t N, int32_t K); /* for the library's own plan */
+int swl_gemm_packed_wide_choose_splits(int32_t M, int32_t N, int32_t K);       /* its choice for k_splits = 0 */
+/* ... stopping at the fp32 partial slabs [k_splits][M][N] (k_splits >= 1) for the split-K consumers */
+int swl_gemm_packed_wide_partial(float *slabs, size_t slabs_bytes, const void *x, const void *w_packed, int32_t M,
+                                 int32_t N, int32_t K, int64_t x_row_stride, int32_t waves_per_group, int32_t k_splits,
+                                 int32_t dtype, swl_stream_t stream);
 /* ... with the SiLU-gate of the FFN (reference kernels/silu_and_mul.py:5-34) in its epilogue: out[M, I] = up * silu(gate) */
 int swl_gemm_packed_wide_silu_gate(void *out, const void *x, const void *w_up_gate_packed, int32_t M, int32_t I,
                                    int32_t K, int64_t x_row_stride, int64_t out_row_stride, int32_t waves_per_group,

@@ -62,6 +62,7 @@ SIGNATURES = {
     "swl_gemm_packed_mid_silu_gate": [_P, _P, _P, _I32, _I32, _I32, _I64, _I64, _I32, _P],
     "swl_gemm_packed_mid": [_P, _P, _P, _P, ctypes.c_size_t, _I32, _I32, _I32, _I64, _I64, _I32, _I32, _P],
     "swl_gemm_packed_wide": [_P, _P, _P, _P, ctypes.c_size_t, _I32, _I32, _I32, _I64, _I64, _I32, _I32, _I32, _P],
+    "swl_gemm_packed_wide_partial": [_P, ctypes.c_size_t, _P, _P, _I32, _I32, _I32, _I64, _I32, _I32, _I32, _P],
     "swl_gemm_packed_wide_silu_gate": [_P, _P, _P, _I32, _I32, _I32, _I64, _I64, _I32, _I32, _P],
     "swl_gemm_skinny_packed_partial": [_P, ctypes.c_size_t, _P, _P, _I32, _I32, _I32, _I64, _I32, _I32, _P],
     "swl_gemm_skinny_packed_silu_gate": [_P, _P, _P, _I32, _I32, _I32, _I64, _I64, _I32, _P],
@@ -92,6 +93,7 @@ _SPECIAL = {
     "swl_gemm_skinny_packed_choose_splits": ([_I32, _I32], _I32),
     "swl_gemm_packed_mid_choose_splits": ([_I32, _I32, _I32], _I32),
     "swl_gemm_packed_wide_workspace_bytes": ([_I32, _I32, _I32], ctypes.c_size_t),
+    "swl_gemm_packed_wide_choose_splits": ([_I32, _I32, _I32], _I32),
     "swl_gemm_tiny_max_tokens": ([], _I32),
 }
 

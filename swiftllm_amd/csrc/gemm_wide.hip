@@ -43,8 +43,10 @@ constexpr int kWT = 64;      // k elements per tile
 
 enum WideMode { kWideDirect = 0, kWidePartial = 1, kWideSiluGate = 2 };
 
+// 4-wave workgroups with more than 4 token blocks run ONE wave per SIMD (launch bound 1: the whole 512-register file per
+// wave — 96-128 accumulator registers, two x register sets and a 6-deep weight ring, 20 KiB per wave in flight).
 template <typename T, int MT, int NWV, int MODE>
-__global__ __launch_bounds__(NWV * 64, 2) void gemm_packed_wide_kernel(
+__global__ __launch_bounds__(NWV * 64, (NWV == 4 && MT > 4) ? 1 : 2) void gemm_packed_wide_kernel(
     void *__restrict__ out_, const T *__restrict__ x, const T *__restrict__ wpk, int M, int N, int K, int kc,
     int64_t x_stride, int64_t out_stride) {
     constexpr int NT = NWV * 64;
@@ -53,8 +55,9 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_packed_wide_kernel(
     constexpr int kXTile = MT * 32 * kWT;
     constexpr int HW = NWV / 2;
     // x prefetch distance in steps: 2 where two register sets fit beside the accumulators, else 1; W ring depth in tiles
-    constexpr int XD = (MT >= 8 || (NWV == 4 && MT >= 6)) ? 1 : 2;
-    constexpr int kWD = (XD == 1 && XL >= 8) ? 3 : 4;
+    constexpr bool kBig = NWV == 4 && MT > 4;    // one wave per SIMD
+    constexpr int XD = (MT >= 8 && !kBig) ? 1 : 2;
+    constexpr int kWD = kBig ? 6 : 4;
     static_assert(MT * 256 % NT == 0, "x tile must split evenly over the workgroup");
     __shared__ __attribute__((aligned(16))) T xs[2 * kXTile];
 
@@ -226,17 +229,17 @@ struct WidePlan {
     int ks;     // K splits (fp32 slabs when > 1)
 };
 
-// Workgroup width and K-split for (M, N, K), from the sweep on MI355X (profiles/r04c_gemm_wide_micro.jsonl, Llama-3-8B
-// widths, bf16, M = 96..256): 4-wave workgroups (two per CU) up to 192 tokens — except the long-K down projection beyond 128
-// tokens — and 8-wave ones above; K split into the largest power of two that keeps a chunk >= 16 K-tiles (4-wave) / 8
-// K-tiles (8-wave) long and the launch at <= 256 workgroups: o / qkv 4 chunks, down 8 at M <= 128; 8 / 8 / 16 with 8 waves.
+// Workgroup width and K-split for (M, N, K), from the sweeps on MI355X (profiles/r04c_/r04d_gemm_wide_micro.jsonl,
+// Llama-3-8B widths, bf16, M = 96..256): 4-wave workgroups everywhere (two per CU up to 128 tokens, one wave per SIMD
+// above — they beat the 8-wave groups at every shape once they had the register file to themselves); K split into the
+// largest power of two that keeps the launch at <= 256 workgroups and a chunk >= 16 K-tiles (<= 128 tokens) / 8 K-tiles
+// long: qkv 4 chunks, o_proj 4 / 8, down 8.
 static WidePlan gemm_wide_plan(int M, int N, int K, int forced_nwv, int forced_ks) {
     WidePlan p;
     const int tiles = N / 32;
-    p.nwv = forced_nwv ? forced_nwv : ((K >= 2 * N && M > 128) ? 8 : 4);
-    if (M > 192) p.nwv = 8;     // 8 token blocks + a 4-wave workgroup's staging registers do not fit 256 VGPRs
+    p.nwv = forced_nwv ? forced_nwv : 4;
     const int wgs = (tiles + p.nwv - 1) / p.nwv;
-    const int min_chunk = (p.nwv == 4 ? 16 : 8) * kWT;
+    const int min_chunk = (M <= 128 ? 16 : 8) * kWT;
     int ks = 1;
     while (ks < 16 && wgs * ks * 2 <= 256 && K % (kWT * ks * 2) == 0 && K / (ks * 2) >= min_chunk) ks *= 2;
     p.ks = forced_ks ? forced_ks : ks;
@@ -255,7 +258,8 @@ static void launch_wide(int mt, int nwv, dim3 grid, hipStream_t s, void *out, co
         else SWL_W_LAUNCH(8, 8);
     } else {
         if (mt <= 4) SWL_W_LAUNCH(4, 4);
-        else SWL_W_LAUNCH(6, 4);        // (mt <= 6: gemm_wide_plan never pairs 4 waves with more)
+        else if (mt <= 6) SWL_W_LAUNCH(6, 4);
+        else SWL_W_LAUNCH(8, 4);
     }
 #undef SWL_W_LAUNCH
 }
@@ -311,9 +315,41 @@ extern "C" int swl_gemm_packed_wide(void *out, const void *x, const void *w_pack
     return swl_splitk_reduce(out, static_cast<const float *>(workspace), p.ks, M, N, out_row_stride, dtype, stream);
 }
 
+/* The split count swl_gemm_packed_wide picks for k_splits = 0 (0 = shape unsupported). */
+extern "C" int swl_gemm_packed_wide_choose_splits(int32_t M, int32_t N, int32_t K) {
+    if (M <= 0 || M > 256 || N <= 0 || K <= 0 || (N & 31) || (K & (swl::kWT - 1))) return 0;
+    return swl::gemm_wide_plan(M, N, K, 0, 0).ks;
+}
+
+/* Partial slabs only (slabs[k_splits][M][N] fp32, k_splits >= 1: a power of two <= 16 with K % (64 * k_splits) == 0) for
+ * the split-K consumers (swl_splitk_fused_add_rmsnorm, swl_splitk_rotary_store_kv_decode): swl_gemm_packed_wide minus its
+ * reduce launch, same bits. */
+extern "C" int swl_gemm_packed_wide_partial(float *slabs, size_t slabs_bytes, const void *x, const void *w_packed,
+                                            int32_t M, int32_t N, int32_t K, int64_t x_row_stride,
+                                            int32_t waves_per_group, int32_t k_splits, int32_t dtype,
+                                            swl_stream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
+    if (M == 0) return SWL_OK;
+    if (!slabs || !x || !w_packed || k_splits < 1 || k_splits > 16 || (k_splits & (k_splits - 1))) return SWL_ERR_BAD_ARG;
+    if (M > 256 || (N & 31) || (K & (swl::kWT - 1)) || K % (swl::kWT * k_splits)) return SWL_ERR_UNSUPPORTED;
+    if (x_row_stride < K || (x_row_stride & 7) || !swl::aligned16(x) || !swl::aligned16(w_packed) || !swl::aligned16(slabs))
+        return SWL_ERR_BAD_ARG;
+    if (static_cast<int64_t>(M) * x_row_stride >= (1ll << 31)) return SWL_ERR_UNSUPPORTED;
+    if (!(waves_per_group == 0 || waves_per_group == 4 || waves_per_group == 8)) return SWL_ERR_BAD_ARG;
+    if (slabs_bytes < static_cast<size_t>(k_splits) * M * N * sizeof(float)) return SWL_ERR_BAD_ARG;
+    const swl::WidePlan p = swl::gemm_wide_plan(M, N, K, waves_per_group, k_splits);
+    const dim3 grid((N / 32 + p.nwv - 1) / p.nwv, p.ks);
+    SWL_DISPATCH_DTYPE(dtype, T, {
+        swl::launch_wide<T, swl::kWidePartial>((M + 31) / 32, p.nwv, grid, static_cast<hipStream_t>(stream), slabs,
+                                               static_cast<const T *>(x), static_cast<const T *>(w_packed), M, N, K,
+                                               K / p.ks, x_row_stride, N);
+    });
+    return swl::check_launch();
+}
+
 /* out[M, I] = up * silu(gate) of x . [up ; gate]^T for up to 256 tokens on a packed weight (the large-batch twin of
  * swl_gemm_skinny_packed_silu_gate; same rounding points as linear + silu_and_mul). I % 32 == 0, K % 64 == 0.
- * waves_per_group: 0 = library's choice (4 up to 192 tokens, 8 above), 4 or 8. */
+ * waves_per_group: 0 = library's choice (4), 4 or 8. */
 extern "C" int swl_gemm_packed_wide_silu_gate(void *out, const void *x, const void *w_up_gate_packed, int32_t M,
                                               int32_t I, int32_t K, int64_t x_row_stride, int64_t out_row_stride,
                                               int32_t waves_per_group, int32_t dtype, swl_stream_t stream) {
@@ -326,7 +362,7 @@ extern "C" int swl_gemm_packed_wide_silu_gate(void *out, const void *x, const vo
     if (!swl::aligned16(x) || !swl::aligned16(w_up_gate_packed) || (reinterpret_cast<uintptr_t>(out) & 7u))
         return SWL_ERR_BAD_ARG;
     if (!(waves_per_group == 0 || waves_per_group == 4 || waves_per_group == 8)) return SWL_ERR_BAD_ARG;
-    const int nwv = M > 192 ? 8 : (waves_per_group ? waves_per_group : 4);
+    const int nwv = waves_per_group ? waves_per_group : 4;
     const int hw = nwv / 2;
     const int mt = (M + 31) / 32;
     const dim3 grid((I / 32 + hw - 1) / hw, 1);

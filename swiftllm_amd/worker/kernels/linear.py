@@ -134,12 +134,20 @@ def _wide_silu_ok(a: torch.Tensor, w: torch.Tensor) -> bool:
 
 
 def _wide_wins(m: int, n: int, k: int) -> bool:
-    """Where the wide kernel beats (or ties) hipBLASLt — profiles/r04c_gemm_wide_micro.jsonl, Llama-3-8B widths, bf16,
-    MI355X, us ours / library: the down projection (K >= 2N) at every M (M = 96: 33 / 63, 128: 34 / 75, 192: 47 / 102,
-    256: 60 / 63); the narrow projections (qkv, o: N <= 8192) up to 192 tokens (128: 24.7 / 26.3 and 21.3 / 22.2; 192:
-    32.9 / 33.9 and 26.3 / 28.4 — at 256 the library's o_proj is 21 against 36). The plain up/gate projection only ties
-    (53.3 / 54.0 at 128) and loses beyond; its SiLU-gate form is decided in `_wide_silu_wins`."""
-    return k >= 2 * n or (n <= 8192 and m <= 192)
+    """Where the wide kernel beats (or ties) hipBLASLt — profiles/r04c_ / r04d_gemm_wide_micro.jsonl, Llama-3-8B widths, bf16,
+    MI355X, us ours / library at M = 96, 128, 160, 192, 224, 256:
+        down (K >= 2N)   33/63  34/75  43/85  44/104  52/60  54/63      -> always
+        qkv  (N = 6144)  23/23  25/26  32/29  32/34   37/37  37/40      -> except (128, 160]
+        o    (N = 4096)  20/20  21/22  26/24  26/29   29/21  30/21      -> up to 128 and (160, 192]
+    (the library's time is far from monotone in M: its 160-token kernels are good, its 192-token ones are not). The plain
+    up/gate projection only ties (53 / 54 at 128) and loses beyond; its SiLU-gate form is decided in `_wide_silu_wins`."""
+    if k >= 2 * n:
+        return True
+    if n > 8192:
+        return False
+    if m <= 128 or 160 < m <= 192:
+        return True
+    return m > 192 and n > 4096
 
 
 def _wide_silu_wins(m: int) -> bool:
@@ -225,6 +233,16 @@ def linear_splitk(a: torch.Tensor, w: torch.Tensor, always: bool = False):
     """Like linear(a, w, skinny=True) but returns SplitKPartials when the kernel splits K (the caller
     hands them to a fused consumer); falls through to `linear` otherwise. `always`: also return the
     partial form (a single fp32 slab) when K is not split — for consumers that only take slabs."""
+    if _wide_ok(a, w) and not always:           # large batch: slabs for the add+norm / rotary+store consumers
+        m, k = a.shape
+        n = w.shape[0]
+        ks = _hip.load().swl_gemm_packed_wide_choose_splits(m, n, k)
+        if ks > 1:
+            ws = _workspace(a.device, ks * m * n * 4)
+            _hip.call("swl_gemm_packed_wide_partial", _hip.ptr(ws), ws.numel() * 4, _hip.ptr(a), _hip.ptr(_packed_of(w)),
+                      m, n, k, _row_stride(a), 0, ks, _hip.dtype_code(a.dtype), _hip.stream())
+            return SplitKPartials(ws, ks, m, n, a.dtype)
+        return linear(a, w, skinny=True)
     if _mid_ok(a, w) and a.shape[0] <= 64:      # medium batch on a packed weight: same contract, own kernel
         m, k = a.shape
         n = w.shape[0]

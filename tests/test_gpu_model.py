@@ -546,3 +546,52 @@ def test_llama32_1b_geometry_matches_oracle(tmp_path, dtype):
                     assert float(top2[0] - top2[1]) <= 2 * float(d[i].max()), (opts, s, i)
         del model
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("batch", [100, 200])
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_large_decode_batches_take_the_wide_kernels_and_match_the_oracle(tmp_path, batch, dtype, monkeypatch):
+    """Decode batches of 65..256 sequences (r04: csrc/gemm_wide.hip): the projections the measured policy gives to
+    swl_gemm_packed_wide really go through it — as split-K slabs into the add+norm / rotary+store consumers where K is
+    split, with the SiLU-gate in the epilogue up to 128 tokens — and the forward still matches the CPU oracle, teacher-
+    forced over 3 steps, on a model wide enough for every K-split rule (hidden 2048, 16/4 heads of 128, FFN 4096)."""
+    from swiftllm_amd import LlamaModelConfig, _hip
+    cfg = synth.make_config(num_hidden_layers=2, hidden_size=2048, num_attention_heads=16, num_key_value_heads=4,
+                            intermediate_size=4096, vocab_size=512, max_position_embeddings=512)
+    tdtype = torch.float16 if dtype == "float16" else torch.bfloat16
+    sd = synth.make_state_dict(cfg, seed=9, dtype=tdtype)
+    ecfg = dict(max_blocks_per_seq=8, max_tokens_in_batch=batch * 24, max_batch_size=batch,
+                max_seqs_in_block_table=batch + 8, dtype=dtype, use_hip_graph=False)
+    model = _make_model(tmp_path, cfg, sd, batch * 3 + 8, **ecfg)
+    ref = RefLlamaModel(LlamaModelConfig(cfg), _engine_config("", **ecfg), sd, tdtype, dense_decode_attention=True)
+    ref.init_kvcache_and_swap(batch * 3 + 8)
+    calls = []
+    real = _hip.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real(name, *a)
+    monkeypatch.setattr(_hip, "call", spy)
+    g = torch.Generator().manual_seed(3)
+    prompts = [torch.randint(0, cfg["vocab_size"], (3 + i % 17,), generator=g).tolist() for i in range(batch)]
+    seq_ids = list(range(batch))
+    got = [model.forward(prompts, seq_ids, [])]
+    want = [ref.forward(prompts, seq_ids, [])]
+    lens = [len(p) for p in prompts]
+    atol, rtol = (2e-3, 2e-3) if dtype == "float16" else (1.6e-2, 1.6e-2)
+    worst = 0.0
+    del calls[:]
+    for i in range(3):
+        lens = [n + 1 for n in lens]
+        got.append(model.forward([[t] for t in got[-1]], seq_ids, list(lens)))
+        want.append(ref.forward([[t] for t in got[-2]], seq_ids, list(lens)))       # teacher-forced with OUR tokens
+        d = (model.post_layer.logits_tap[-1].float().cpu() - ref.last_logits).abs() - rtol * ref.last_logits.abs()
+        worst = max(worst, d.max().item())
+    assert worst <= atol, worst
+    mism = sum(a != b for x, y in zip(got[1:], want[1:]) for a, b in zip(x, y))
+    assert mism <= 1, mism          # (a 512-way argmax over random logits: at most one near-tie in 3 x batch rows)
+    wide = [c for c in calls if c.startswith("swl_gemm_packed_wide")]
+    assert "swl_gemm_packed_wide_partial" in wide, sorted(set(calls))        # K-split projections feed the consumers
+    assert "swl_splitk_fused_add_rmsnorm" in calls
+    assert ("swl_splitk_rotary_store_kv_decode" in calls) == (batch <= 128)      # (qkv beyond 128 tokens: library GEMM here)
+    assert ("swl_gemm_packed_wide_silu_gate" in wide) == (batch <= 128), sorted(set(wide))

@@ -53,9 +53,6 @@ def main():
             for nw, ks in variants:
                 if ks and (K % (64 * ks) or K // ks < 256):
                     continue
-                if M > 192 and nw == 4:
-                    continue
-
                 def run(i, nw=nw, ks=ks):
                     _hip.call("swl_gemm_packed_wide", out.data_ptr(), x.data_ptr(), wps[i % copies].data_ptr(),
                               scratch.data_ptr(), scratch.numel() * 4, M, N, K, K, N, nw, ks, code, _hip.stream())
@@ -76,9 +73,6 @@ def main():
                     return r[:, :I] * F.silu(r[:, I:])
                 row["blas_plus_silu_us"] = round(time_us(blas_pair, a.iters), 2)
                 for nw in (4, 8):
-                    if M > 192 and nw == 4:
-                        continue
-
                     def run(i, nw=nw):
                         _hip.call("swl_gemm_packed_wide_silu_gate", og.data_ptr(), x.data_ptr(), wps[i % copies].data_ptr(),
                                   M, I, K, K, I, nw, code, _hip.stream())

@@ -39,8 +39,15 @@ Extra objects on the JSON line:
                   oracle/_ref is absent.
   configs1_batch1 / configs3_llama2_7b_4x16k   (rank 0, N=1) short driver-measured runs of BASELINE configs[1]
                   and configs[3] (KV pre-filled, no 16k prefill).
-  cpu_baseline    rank 0, N=1 only: the CPU oracle's forward (oracle/ref_model.py — the reference has no CPU path
-                  of its own) on the host cores, on a bounded sample.
+  cpu_baseline    rank 0, N=1 only: the CPU oracle's decode forward (oracle/ref_model.py — the reference has no CPU path
+                  of its own) on the host cores at FULL depth (all layers timed, nothing extrapolated):
+                  one warm-up + 2 timed steps at the bench's batch and mean timed context (~8 s per step on 128 threads).
+  prefill_roofline / prefill_attention_roofline   the prompt forward against the dense MFMA peak (executed flops / wall
+                  time; ~90 % of it is hipBLASLt, the reference's own call) and the hand-written prefill attention kernel
+                  alone (HIP events on its launch stream, causal flops / mean launch).
+  decode_batch128 / decode_batch256   (rank 0, N=1) decode-only steps at the batch sizes the 264 GB pool is sized for
+                  (projections on csrc/gemm_wide.hip where it beats the library), with step_roofline.
+  reference_triton also carries the reference's prompt pass (prefill_tok_s) from the same child process.
 """
 import argparse
 import contextlib

@@ -578,16 +578,19 @@ def test_large_decode_batches_take_the_wide_kernels_and_match_the_oracle(tmp_pat
     got = [model.forward(prompts, seq_ids, [])]
     want = [ref.forward(prompts, seq_ids, [])]
     lens = [len(p) for p in prompts]
-    atol, rtol = (2e-3, 2e-3) if dtype == "float16" else (1.6e-2, 1.6e-2)
+    mant = 10 if dtype == "float16" else 7
     worst = 0.0
     del calls[:]
     for i in range(3):
         lens = [n + 1 for n in lens]
         got.append(model.forward([[t] for t in got[-1]], seq_ids, list(lens)))
         want.append(ref.forward([[t] for t in got[-2]], seq_ids, list(lens)))       # teacher-forced with OUR tokens
-        d = (model.post_layer.logits_tap[-1].float().cpu() - ref.last_logits).abs() - rtol * ref.last_logits.abs()
-        worst = max(worst, d.max().item())
-    assert worst <= atol, worst
+        d = (model.post_layer.logits_tap[-1].float().cpu() - ref.last_logits).abs().amax(dim=1)
+        row_ulp = torch.exp2(torch.floor(torch.log2(ref.last_logits.abs().amax(dim=1))) - mant)
+        worst = max(worst, float((d / row_ulp).max()))
+    # the bar of tests/test_gpu_parity_fullwidth.py: within 3 ulps of the storage dtype at the row's scale of the CPU oracle
+    # (hipBLASLt / MFMA vs CPU fp32 summation order: 1-ulp flips of 16-bit activations that propagate; measured r04: 1-2 ulps)
+    assert worst <= 3.0, worst
     mism = sum(a != b for x, y in zip(got[1:], want[1:]) for a, b in zip(x, y))
     assert mism <= 1, mism          # (a 512-way argmax over random logits: at most one near-tie in 3 x batch rows)
     wide = [c for c in calls if c.startswith("swl_gemm_packed_wide")]

@@ -2,7 +2,8 @@
 
 Model: Llama-3-8B layer geometry (hidden 4096, 32 q / 8 kv heads of 128, FFN 14336, rope_theta 5e5), 2 layers,
 8k vocabulary (so the CPU side stays small). Workloads: BASELINE.json configs[1] (batch 1, 1024-token prompt,
-greedy decode) and a configs[2]-shaped ragged batch of 32 (lengths 1..1024). The HIP data plane — default path,
+8 greedy steps) and a configs[2]-shaped ragged batch of 32 (lengths 1..1024, 3 steps; r02-r03 ran 12 / 5 steps: the
+per-step distances do not grow with the step, profiles/r02_parity_fullwidth_*). The HIP data plane — default path,
 hipGraph replay, row-major (unpacked) decode weights — is compared with oracle/ref_model.py, which is pinned to the
 reference's own run on the tiny golden (tests/test_oracle_golden.py), in BOTH decode-score modes (the default path
 defers the RMSNorm scale into the consuming projection, `exact_rmsnorm_rounding` keeps the reference's rounding points):
@@ -39,9 +40,9 @@ CFG = dict(num_hidden_layers=2, hidden_size=4096, num_attention_heads=32, num_ke
            intermediate_size=14336, vocab_size=8192, max_position_embeddings=2048, rope_theta=500000.0)
 CASES = {
     # name: (prompt lengths, decode steps)
-    "configs1_batch1": ([1024], 12),
+    "configs1_batch1": ([1024], 8),
     "configs2_batch32": ([1024, 1, 15, 16, 17, 100, 257, 640, 33, 1000, 511, 512, 513, 64, 128, 900,
-                          1024, 2, 31, 48, 300, 700, 800, 5, 1023, 256, 255, 77, 450, 999, 10, 129], 5),
+                          1024, 2, 31, 48, 300, 700, 800, 5, 1023, 256, 255, 77, 450, 999, 10, 129], 3),
 }
 VARIANTS = (("default", dict()), ("eager_launches", dict(use_hip_graph=False)),
             ("row_major_weights", dict(pack_decode_weights=False)),
@@ -175,7 +176,7 @@ def test_full_width_logits_hold_the_absolute_1e3_bar_when_it_is_meaningful(tmp_p
     fp16 ulp (spacing 3.9e-3) — not a bar any fp16 implementation, the reference's own two paths included, can be held
     to. Here the SAME Llama-3-8B-width model (hidden 4096, 32/8 heads of 128, FFN 14336, 2 layers, batch 32 at ~1k
     contexts, fp16) gets an lm_head drawn `shrink` times smaller so that 1e-3 is a real bound, and it is ASSERTED for
-    prefill + 5 decode steps:
+    prefill + 3 decode steps:
       * |logit| <= 0.5 (1e-3 >= 4 fp16 ulps): ours is within 1e-3 of the CPU oracle with exact scores (measured 4.9e-4).
         The compiled reference itself is 1.66e-3 from that oracle here — it rounds decode scores to fp16
         (paged_attn.py:72-73) — so ours-vs-reference (1.62e-3) is bounded by the triangle 1e-3 + the reference's own

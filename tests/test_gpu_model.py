@@ -579,7 +579,7 @@ def test_large_decode_batches_take_the_wide_kernels_and_match_the_oracle(tmp_pat
     want = [ref.forward(prompts, seq_ids, [])]
     lens = [len(p) for p in prompts]
     mant = 10 if dtype == "float16" else 7
-    worst = 0.0
+    worst, mism, off_tie = 0.0, 0, []
     del calls[:]
     for i in range(3):
         lens = [n + 1 for n in lens]
@@ -588,11 +588,16 @@ def test_large_decode_batches_take_the_wide_kernels_and_match_the_oracle(tmp_pat
         d = (model.post_layer.logits_tap[-1].float().cpu() - ref.last_logits).abs().amax(dim=1)
         row_ulp = torch.exp2(torch.floor(torch.log2(ref.last_logits.abs().amax(dim=1))) - mant)
         worst = max(worst, float((d / row_ulp).max()))
+        top2 = ref.last_logits.topk(2, dim=1).values
+        for r, (a, b) in enumerate(zip(got[-1], want[-1])):
+            if a != b:      # a greedy id may differ only on a near-tie of the oracle: top-2 gap within twice the row's distance
+                mism += 1
+                if float(top2[r, 0] - top2[r, 1]) > 2 * float(d[r]):
+                    off_tie.append((i, r, float(top2[r, 0] - top2[r, 1]), float(d[r])))
     # the bar of tests/test_gpu_parity_fullwidth.py: within 3 ulps of the storage dtype at the row's scale of the CPU oracle
     # (hipBLASLt / MFMA vs CPU fp32 summation order: 1-ulp flips of 16-bit activations that propagate; measured r04: 1-2 ulps)
     assert worst <= 3.0, worst
-    mism = sum(a != b for x, y in zip(got[1:], want[1:]) for a, b in zip(x, y))
-    assert mism <= 1, mism          # (a 512-way argmax over random logits: at most one near-tie in 3 x batch rows)
+    assert not off_tie and mism <= 3 * batch // 50, (mism, off_tie)
     wide = [c for c in calls if c.startswith("swl_gemm_packed_wide")]
     assert "swl_gemm_packed_wide_partial" in wide, sorted(set(calls))        # K-split projections feed the consumers
     assert "swl_splitk_fused_add_rmsnorm" in calls

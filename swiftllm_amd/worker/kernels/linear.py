@@ -189,7 +189,7 @@ def linear(a: torch.Tensor, w: torch.Tensor, skinny: bool = False) -> torch.Tens
                   ws.numel() * 4 if ws is not None else 0, m, n, k, _row_stride(a), n, 0,
                   _hip.dtype_code(a.dtype), _hip.stream())
         return out
-    return _blas_linear(a, w, skinny=skinny)
+    return _blas_linear(a, w)
 
 
 # hipBLASLt's cost per token is far from flat in the token count M (Llama-3-8B widths, bf16, MI355X,
@@ -206,18 +206,7 @@ _BLAS_ROW_BLOCKS = (8192, 4096)
 _BLAS_PLATEAU_ROWS = 16384
 
 
-_side_streams = {}          # device -> side stream for the decode-sized tail of a piggybacked GEMM
-_TAIL_MAX_ROWS = 256
-
-
-def _side_stream(device: torch.device) -> "torch.cuda.Stream":
-    st = _side_streams.get(device)
-    if st is None:
-        st = _side_streams[device] = torch.cuda.Stream(device=device)
-    return st
-
-
-def _blas_linear(a: torch.Tensor, w: torch.Tensor, row_blocks=None, plateau=None, skinny: bool = False) -> torch.Tensor:
+def _blas_linear(a: torch.Tensor, w: torch.Tensor, row_blocks=None, plateau=None) -> torch.Tensor:
     blocks = _BLAS_ROW_BLOCKS if row_blocks is None else row_blocks
     if a.dim() != 2 or not blocks or a.shape[0] <= min(blocks):
         return F.linear(a, w)
@@ -227,24 +216,6 @@ def _blas_linear(a: torch.Tensor, w: torch.Tensor, row_blocks=None, plateau=None
         return F.linear(a, w)
     out = torch.empty((m, w.shape[0]), dtype=a.dtype, device=a.device)
     wt = w.t()
-    # Piggybacked batches (reference transformer_layer.py:78-114: prompt tokens first, then one row per decoding sequence):
-    # 4 x 1024 prompt rows + 28 decode rows split into a 4096-row block and a 28-row tail. The tail is a decode-sized
-    # projection — pure weight streaming, HBM-bound — while the block before it is MFMA-bound and leaves the memory
-    # system idle: the tail runs on a side stream on the hand-written decode kernels (the bits a pure-decode step gives
-    # those rows) next to the library GEMM of the block, instead of after it (r04; r03 ran it as a second library call:
-    # ~100 us per layer at 28 rows, the whole distance between a mixed step and its prompt-only half).
-    tail = m % unit
-    tail_done = None
-    if (skinny and 0 < tail <= _TAIL_MAX_ROWS and m < plateau and a.is_cuda and not torch.cuda.is_current_stream_capturing()
-            and (_packed_of(w) is not None or _skinny_ok(a[m - tail:], w))):
-        side, ready = _side_stream(a.device), torch.cuda.Event()
-        ready.record()
-        with torch.cuda.stream(side):
-            side.wait_event(ready)
-            out[m - tail:].copy_(linear(a[m - tail:], w, skinny=True))
-            tail_done = torch.cuda.Event()
-            tail_done.record()
-        m -= tail
     start = 0
     if m >= plateau:
         start = m // unit * unit
@@ -254,9 +225,7 @@ def _blas_linear(a: torch.Tensor, w: torch.Tensor, row_blocks=None, plateau=None
             torch.mm(a[start:start + size], wt, out=out[start:start + size])
             start += size
     if start < m:
-        torch.mm(a[start:m], wt, out=out[start:m])
-    if tail_done is not None:
-        torch.cuda.current_stream().wait_event(tail_done)
+        torch.mm(a[start:], wt, out=out[start:])
     return out
 
 

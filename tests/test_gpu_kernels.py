@@ -783,32 +783,6 @@ def test_gemm_packed_mid_silu_gate_equals_two_ops(dtype, M, I, Kd):
     assert torch.equal(fused, two[:, :I])
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tail", [28, 1, 100])
-def test_piggybacked_gemm_tail_runs_on_the_decode_kernels_beside_the_prompt_block(dtype, tail):
-    """kernels/linear.py: _blas_linear — a piggybacked batch of 4096 prompt rows + `tail` decode rows: the prompt block is the
-    library GEMM, the tail the hand-written decode kernel on a side stream (r04). Rows are independent: the prompt rows
-    carry the bits of F.linear on those rows, the tail rows the bits of linear(tail rows, skinny=True) — what a pure-decode
-    step gives them — and nothing is left running on the side stream when the call returns."""
-    from swiftllm_amd.worker.kernels import linear as L
-    g = gen(tail)
-    n, k = 4096, 4096
-    w = (torch.randn(n, k, generator=g) * 0.02).to(dtype).cuda()
-    L.pack_weight(w)
-    a = torch.randn(4096 + tail, k, generator=g).to(dtype).cuda()
-    out = L.linear(a, w, skinny=True)
-    torch.cuda.current_stream().synchronize()           # (only the CALLER's stream: the tail must already be ordered into it)
-    assert torch.equal(out[:4096], torch.nn.functional.linear(a[:4096], w))
-    assert torch.equal(out[4096:], L.linear(a[4096:].contiguous(), w, skinny=True))
-    ref = a.float() @ w.float().T
-    eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
-    assert ((out.float() - ref).abs() <= eps * ref.abs() + 1e-3 * eps * (k ** 0.5)).all()
-    # without the decode kernels (skinny=False: the reference's BLAS calls) the tail is a second library call, as in r03
-    plain = L.linear(a, w, skinny=False)
-    assert torch.equal(plain[:4096], out[:4096])
-    assert ((plain.float() - ref).abs() <= eps * ref.abs() + 1e-3 * eps * (k ** 0.5)).all()
-
-
 # ---- large decode batches: 64 < M <= 256 tokens on packed weights (csrc/gemm_wide.hip) -------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M", [65, 100, 128, 129, 192, 193, 256, 40])

@@ -580,3 +580,53 @@ def test_reference_harness_plans_keep_the_scripts_sequence_order():
         assert t == want_t and torch.equal(lg, want_l), (split, reverse)
         assert len(fake.calls) == min(split, 3)
         assert sorted(s for c in fake.calls for s in c[0]) == sorted(seq_ids)
+
+
+def test_affinity_plan_says_which_rule_it_applied(monkeypatch):
+    """dp.affinity_plan (r04): eight replicas never share cores — NUMA-local cores when the KFD topology is
+    readable, an even contiguous split of the allowed cores when it is not — and the reason travels with the core list
+    (bench.py prints it as config.cpu_affinity)."""
+    from swiftllm_amd import dp
+    allowed = list(range(64))
+    monkeypatch.setattr(dp, "_gpu_numa_nodes", lambda: [])
+    seen = []
+    for r in range(8):
+        cpus, how = dp.affinity_plan(r, 8, allowed)
+        assert len(cpus) == 8 and "even split" in how and "unreadable" in how
+        seen += cpus
+    assert sorted(seen) == allowed
+    monkeypatch.setattr(dp, "_gpu_numa_nodes", lambda: [-1] * 8)
+    assert "reported as" in dp.affinity_plan(3, 8, allowed)[1]
+    cpus, how = dp.affinity_plan(0, 1, allowed)
+    assert cpus == allowed and "single replica" in how
+
+
+def test_spawn_local_ranks_kills_a_rank_that_ignores_sigterm(monkeypatch):
+    """a surviving rank stuck in a HIP call (here: ignoring SIGTERM) must not make the launcher spin for ever —
+    terminate, a grace period, then kill; the timeout is a monotonic deadline."""
+    import sys
+    import time
+    from swiftllm_amd import dp
+    monkeypatch.setattr(dp, "TERMINATE_GRACE_S", 0.5)
+    stubborn = ("import os, signal, sys, time\n"
+                "signal.signal(signal.SIGTERM, signal.SIG_IGN)\n"
+                "sys.exit(3) if os.environ['RANK'] == '0' else time.sleep(60)\n")
+    t0 = time.monotonic()
+    rc = dp.spawn_local_ranks([sys.executable, "-c", stubborn], 2, visible_devices=["0", "0"])
+    assert rc == 3 and time.monotonic() - t0 < 20
+    sleeper = "import signal, time\nsignal.signal(signal.SIGTERM, signal.SIG_IGN)\ntime.sleep(60)\n"
+    t0 = time.monotonic()
+    rc = dp.spawn_local_ranks([sys.executable, "-c", sleeper], 2, timeout_s=1.0, visible_devices=["0", "0"])
+    assert rc == 124 and time.monotonic() - t0 < 20
+
+
+def test_wide_gemm_routing_is_the_measured_table():
+    """kernels/linear.py: _wide_wins / _wide_silu_wins encode profiles/r04c_/r04d_gemm_wide_micro.jsonl (Llama-3-8B widths)."""
+    from swiftllm_amd.worker.kernels.linear import _wide_wins, _wide_silu_wins
+    qkv, o, up_gate, down, lm_head = (6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336), (128256, 4096)
+    for m in (65, 96, 128, 160, 192, 224, 256):
+        assert _wide_wins(m, *down)
+        assert not _wide_wins(m, *up_gate) and not _wide_wins(m, *lm_head)
+    assert [_wide_wins(m, *qkv) for m in (96, 128, 160, 192, 224, 256)] == [True, True, False, True, True, True]
+    assert [_wide_wins(m, *o) for m in (96, 128, 160, 192, 224, 256)] == [True, True, False, True, False, False]
+    assert [_wide_silu_wins(m) for m in (96, 128, 129, 256)] == [True, True, False, False]

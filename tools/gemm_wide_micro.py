@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--dtype", default="bfloat16")
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--copies", type=int, default=6)
+    ap.add_argument("--auto-only", action="store_true", help="the library's own plan only, no hipBLASLt timing (for PMC passes)")
     a = ap.parse_args()
     dtype = getattr(torch, a.dtype)
     code = _hip.dtype_code(dtype)
@@ -46,10 +47,11 @@ def main():
             x = torch.randn(M, K, device="cuda", generator=g).to(dtype)
             ref = x.float() @ ws[0].float().t()
             row = dict(shape=name, M=M, N=N, K=K, MB=round(N * K * 2 / 1e6, 1))
-            row["blas_us"] = round(time_us(lambda i: F.linear(x, ws[i % copies]), a.iters), 2)
+            if not a.auto_only:
+                row["blas_us"] = round(time_us(lambda i: F.linear(x, ws[i % copies]), a.iters), 2)
             out = torch.empty(M, N, device="cuda", dtype=dtype)
             scratch = _workspace(x.device, 16 * M * N * 4)
-            variants = [(0, 0)] + [(nw, ks) for nw in (4, 8) for ks in (1, 2, 4, 8, 16)]
+            variants = [(0, 0)] + ([] if a.auto_only else [(nw, ks) for nw in (4, 8) for ks in (1, 2, 4, 8, 16)])
             for nw, ks in variants:
                 if ks and (K % (64 * ks) or K // ks < 256):
                     continue
@@ -71,8 +73,9 @@ def main():
                 def blas_pair(i):
                     r = F.linear(x, ws[i % copies])
                     return r[:, :I] * F.silu(r[:, I:])
-                row["blas_plus_silu_us"] = round(time_us(blas_pair, a.iters), 2)
-                for nw in (4, 8):
+                if not a.auto_only:
+                    row["blas_plus_silu_us"] = round(time_us(blas_pair, a.iters), 2)
+                for nw in ((0,) if a.auto_only else (4, 8)):
                     def run(i, nw=nw):
                         _hip.call("swl_gemm_packed_wide_silu_gate", og.data_ptr(), x.data_ptr(), wps[i % copies].data_ptr(),
                                   M, I, K, K, I, nw, code, _hip.stream())

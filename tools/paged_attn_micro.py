@@ -27,6 +27,8 @@ SHAPES = {  # H, KVH, D, batch, len, layers kept resident
     "c3": (32, 8, 128, 32, 1088, 32),
     "c4": (32, 32, 128, 4, 16384, 4),
     "c3_b128": (32, 8, 128, 128, 1088, 8),
+    "c3_b64": (32, 8, 128, 64, 1088, 16),
+    "c3_b256": (32, 8, 128, 256, 1088, 4),
     "long": (32, 8, 128, 1, 131072, 8),
 }
 

@@ -630,3 +630,19 @@ def test_wide_gemm_routing_is_the_measured_table():
     assert [_wide_wins(m, *qkv) for m in (96, 128, 160, 192, 224, 256)] == [True, True, False, True, True, True]
     assert [_wide_wins(m, *o) for m in (96, 128, 160, 192, 224, 256)] == [True, True, False, True, False, False]
     assert [_wide_silu_wins(m) for m in (96, 128, 129, 256)] == [True, True, False, False]
+
+
+def test_bench_prefill_flops_and_full_depth_cpu_baseline():
+    """bench.py: the flop count behind `prefill_roofline` (SURVEY.md §8d arithmetic: projections on every token, causal
+    attention, lm_head on the last tokens) and the full-depth CPU baseline leg (all layers timed, nothing extrapolated)."""
+    import bench
+    cfg = bench.model_config_dict("llama3-8b")
+    gemm, attn = bench.prefill_flops(cfg, [1024] * 32)
+    L, h, I, V, kvd = 32, 4096, 14336, 128256, 1024
+    assert gemm == 2 * L * (2 * h * h + 2 * kvd * h + 3 * I * h) * 32768 + 2 * 32 * V * h
+    assert attn == L * 32 * 2 * 1024 * 1024 * 128 * 32
+    assert gemm + attn == 466226551717888                      # the figure in profiles/r04*_bench_*.json
+    tiny = bench.model_config_dict("tiny")
+    out = bench.cpu_baseline(tiny, 2, 40, "bfloat16", steps=1)
+    assert out["kind"] == "port" and out["extrapolated"] is False and out["value"] > 0
+    assert "2 layers, all timed" in out["sample"]

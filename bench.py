@@ -342,7 +342,7 @@ def attention_roofline(model, lens, iters):
     slab_bytes = part.k_splits * B * part.shape[1] * 4 if isinstance(part, SplitKPartials) else B * H * D * e
     alg_bytes = kv_bytes + slab_bytes + B * H * D * e + part_bytes
     gbs = alg_bytes / (us * 1e-6) / 1e9
-    pmc_name = "r03_paged_attn_qkv_pmc.json" if isinstance(part, SplitKPartials) else "r01_paged_attn_pmc.json"
+    pmc_name = "r04_paged_attn_qkv_pmc.json" if isinstance(part, SplitKPartials) else "r01_paged_attn_pmc.json"
     traffic, src = _pmc_traffic(pmc_name, alg_bytes, (H, KVH, D) == (32, 8, 128) and nsb == 1)
     return dict(bound="hbm", kernel=entry, achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(gbs / HBM_PEAK_GBS, 4), frac_of_measured_copy=round(gbs / HBM_COPY_GBS, 4),
@@ -374,7 +374,7 @@ def gemm_roofline(model, batch, iters):
     e = model.dtype.itemsize
     alg_bytes = 2 * I * K * e + M * K * e + M * I * e
     gbs = alg_bytes / (us * 1e-6) / 1e9
-    pmc_name = "r03_gemm_silu_packed_pmc.json" if packed else "r01e_gemm_silu_pmc.json"
+    pmc_name = "r04_gemm_silu_packed_pmc.json" if packed else "r01e_gemm_silu_pmc.json"
     traffic, src = _pmc_traffic(pmc_name, alg_bytes, (I, K) == (14336, 4096) and model.dtype == torch.bfloat16)
     return dict(bound="hbm", kernel="%s (gemm_skinny_ring_kernel<SiluGate%s>: up/gate projection + SiLU-gate)" % (fn, ", packed W" if packed else ""),
                 achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),

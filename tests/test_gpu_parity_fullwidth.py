@@ -138,6 +138,8 @@ def test_full_width_forward_matches_oracle(tmp_path, case, dtype):
     noise_ulp = max(r["max_ulp_of_row"] for r in report["noise_floor_ref_scores_vs_exact"])
     failures = []
     for name, opts in VARIANTS:
+        if batch > 1 and name in ("eager_launches", "row_major_weights"):
+            continue        # (suite time: both run at batch 1 here; graph == eager bit-equality at batch 32 is tests/test_gpu_model.py's)
         toks, logits = run_hip(opts)
         rows = compare(toks, logits)
         report[name] = rows

@@ -233,11 +233,11 @@ def linear_splitk(a: torch.Tensor, w: torch.Tensor, always: bool = False):
     """Like linear(a, w, skinny=True) but returns SplitKPartials when the kernel splits K (the caller
     hands them to a fused consumer); falls through to `linear` otherwise. `always`: also return the
     partial form (a single fp32 slab) when K is not split — for consumers that only take slabs."""
-    if _wide_ok(a, w) and not always:           # large batch: slabs for the add+norm / rotary+store consumers
+    if _wide_ok(a, w):                          # large batch: slabs for the add+norm / slab-fed attention consumers
         m, k = a.shape
         n = w.shape[0]
         ks = _hip.load().swl_gemm_packed_wide_choose_splits(m, n, k)
-        if ks > 1:
+        if ks > 1 or (always and ks == 1):
             ws = _workspace(a.device, ks * m * n * 4)
             _hip.call("swl_gemm_packed_wide_partial", _hip.ptr(ws), ws.numel() * 4, _hip.ptr(a), _hip.ptr(_packed_of(w)),
                       m, n, k, _row_stride(a), 0, ks, _hip.dtype_code(a.dtype), _hip.stream())

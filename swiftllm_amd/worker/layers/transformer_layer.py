@@ -92,7 +92,7 @@ class LlamaTransformerLayer:
     def _slab_fed_attention_applies(self, st) -> bool:
         """Pure-decode batch on the path `fused qkv slabs -> (rotary + KV store + paged attention)` in one launch."""
         cfg, ecfg, w = self.model_config, self.engine_config, self.weight
-        return (self.skinny and st.num_prefill_seqs == 0 and 0 < st.num_decoding_seqs <= 64 and not st.ignore_kvcache
+        return (self.skinny and st.num_prefill_seqs == 0 and 0 < st.num_decoding_seqs <= 256 and not st.ignore_kvcache
                 and st.position_indices is not None and getattr(ecfg, "fuse_rope_kvstore", False)
                 and getattr(ecfg, "fuse_splitk_consumers", True) and w.qkv_proj is not None
                 and getattr(ecfg, "fuse_rope_into_attention", True) and cfg.head_dim in (32, 64, 128))
@@ -165,7 +165,7 @@ class LlamaTransformerLayer:
         fast = self.skinny and pure_decode and getattr(ecfg, "fuse_splitk_consumers", True)
         qkv = None
         if (fast and fused_rope_store and w.qkv_proj is not None and getattr(ecfg, "fuse_rope_into_attention", True)
-                and cfg.head_dim in (32, 64, 128) and st.num_decoding_seqs <= 64):   # (the slab-fed kernel's batch range)
+                and cfg.head_dim in (32, 64, 128) and st.num_decoding_seqs <= 256):  # (batches the slab-producing GEMMs serve)
             # fused qkv slabs -> (rotary + KV store + paged attention) in one launch
             qkv = linear_splitk(input_embds, w.qkv_proj, always=True)
             if isinstance(qkv, SplitKPartials):

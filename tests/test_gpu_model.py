@@ -552,7 +552,7 @@ def test_llama32_1b_geometry_matches_oracle(tmp_path, dtype):
 @pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
 def test_large_decode_batches_take_the_wide_kernels_and_match_the_oracle(tmp_path, batch, dtype, monkeypatch):
     """Decode batches of 65..256 sequences (r04: csrc/gemm_wide.hip): the projections the measured policy gives to
-    swl_gemm_packed_wide really go through it — as split-K slabs into the add+norm / rotary+store consumers where K is
+    swl_gemm_packed_wide really go through it — as split-K slabs into the add+norm consumer and the slab-fed attention kernel where K is
     split, with the SiLU-gate in the epilogue up to 128 tokens — and the forward still matches the CPU oracle, teacher-
     forced over 3 steps, on a model wide enough for every K-split rule (hidden 2048, 16/4 heads of 128, FFN 4096)."""
     from swiftllm_amd import LlamaModelConfig, _hip
@@ -601,5 +601,8 @@ def test_large_decode_batches_take_the_wide_kernels_and_match_the_oracle(tmp_pat
     wide = [c for c in calls if c.startswith("swl_gemm_packed_wide")]
     assert "swl_gemm_packed_wide_partial" in wide, sorted(set(calls))        # K-split projections feed the consumers
     assert "swl_splitk_fused_add_rmsnorm" in calls
-    assert ("swl_splitk_rotary_store_kv_decode" in calls) == (batch <= 128)      # (qkv beyond 128 tokens: library GEMM here)
+    # up to 128 tokens the qkv slabs go straight into the attention kernel's prologue (rotary + KV store + attention in one
+    # launch); beyond, this model's qkv projection is the library's and the separate rotary+store launch runs
+    assert ("swl_paged_attn_decode_qkv" in calls) == (batch <= 128), sorted(set(calls))
+    assert ("swl_rotary_store_kv_decode" in calls or "swl_splitk_rotary_store_kv_decode" in calls) == (batch > 128)
     assert ("swl_gemm_packed_wide_silu_gate" in wide) == (batch <= 128), sorted(set(wide))

@@ -606,3 +606,29 @@ def test_large_decode_batches_take_the_wide_kernels_and_match_the_oracle(tmp_pat
     assert ("swl_paged_attn_decode_qkv" in calls) == (batch <= 128), sorted(set(calls))
     assert ("swl_rotary_store_kv_decode" in calls or "swl_splitk_rotary_store_kv_decode" in calls) == (batch > 128)
     assert ("swl_gemm_packed_wide_silu_gate" in wide) == (batch <= 128), sorted(set(wide))
+
+
+@pytest.mark.parametrize("batch", [100, 200])
+def test_large_decode_batches_replay_their_hip_graph_bit_for_bit(tmp_path, batch):
+    """The product default (hipGraph replay) at decode batches beyond 64: the captured graph — wide GEMMs, their slabs into
+    the add+norm consumer and the slab-fed attention prologue — gives the tokens AND the logits of eager launches, bit for
+    bit, over 4 steps (bfloat16, the geometry of the test above)."""
+    cfg = synth.make_config(num_hidden_layers=2, hidden_size=2048, num_attention_heads=16, num_key_value_heads=4,
+                            intermediate_size=4096, vocab_size=512, max_position_embeddings=512)
+    sd = synth.make_state_dict(cfg, seed=9, dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(3)
+    prompts = [torch.randint(0, cfg["vocab_size"], (3 + i % 17,), generator=g).tolist() for i in range(batch)]
+    runs = {}
+    for graph in (False, True):
+        model = _make_model(tmp_path / f"g{int(graph)}", cfg, sd, batch * 3 + 8, max_blocks_per_seq=8,
+                            max_tokens_in_batch=batch * 24, max_batch_size=batch, max_seqs_in_block_table=batch + 8,
+                            dtype="bfloat16", use_hip_graph=graph)
+        toks = _run_script(model, prompts, 4)
+        runs[graph] = (toks, [t.clone() for t in model.post_layer.logits_tap])
+        if graph:
+            assert len(model._decode_graphs) >= 1
+        del model
+        torch.cuda.empty_cache()
+    assert runs[True][0] == runs[False][0]
+    for a, b in zip(runs[True][1], runs[False][1]):
+        assert torch.equal(a, b)

@@ -45,17 +45,11 @@ enum WideMode { kWideDirect = 0, kWidePartial = 1, kWideSiluGate = 2 };
 
 // 4-wave workgroups with more than 4 token blocks run ONE wave per SIMD (launch bound 1: the whole 512-register file per
 // wave — 96-128 accumulator registers, two x register sets and a 6-deep weight ring, 20 KiB per wave in flight).
-//
-// KH = 2 (r04, <= 4 token blocks): the workgroup's K-chunk is halved between two groups of NWV waves — twice the waves,
-// hence twice the weight bytes in flight per CU, for launches that cannot put more than one 4-wave workgroup on a CU
-// (the up/gate projection: 224 workgroups; 4 waves x 12 KiB in flight streamed at 4.4 TB/s). Each half stages its own x
-// tiles; at the end the second half hands its accumulators to the first through LDS (fp32, one add per output: the
-// summation order of a 2-way K split, deterministic).
-template <typename T, int MT, int NWV, int MODE, int KH = 1>
-__global__ __launch_bounds__(NWV * KH * 64, (NWV == 4 && MT > 4) ? 1 : 2) void gemm_packed_wide_kernel(
+template <typename T, int MT, int NWV, int MODE>
+__global__ __launch_bounds__(NWV * 64, (NWV == 4 && MT > 4) ? 1 : 2) void gemm_packed_wide_kernel(
     void *__restrict__ out_, const T *__restrict__ x, const T *__restrict__ wpk, int M, int N, int K, int kc,
     int64_t x_stride, int64_t out_stride) {
-    constexpr int NT = NWV * 64;                 // threads of one K-half: they stage that half's x tile
+    constexpr int NT = NWV * 64;
     constexpr int XL = MT * 256 / NT;            // 16-byte chunks of the x tile each thread stages
     constexpr int RPP = NT / 8;                  // rows per staging pass (8 chunks per row)
     constexpr int kXTile = MT * 32 * kWT;
@@ -65,23 +59,18 @@ __global__ __launch_bounds__(NWV * KH * 64, (NWV == 4 && MT > 4) ? 1 : 2) void g
     constexpr int XD = (MT >= 8 && !kBig) ? 1 : 2;
     constexpr int kWD = kBig ? 6 : 4;
     static_assert(MT * 256 % NT == 0, "x tile must split evenly over the workgroup");
-    static_assert(KH == 1 || (KH == 2 && MT <= 4 && NWV == 4), "K-halved groups: 4 row waves, <= 4 token blocks");
-    static_assert(KH == 1 || NWV * MT * 16 * 64 * 4 <= KH * 2 * kXTile * 2, "the hand-over tiles must fit the x buffers");
-    __shared__ __attribute__((aligned(16))) T xs_all[KH * 2 * kXTile];
+    __shared__ __attribute__((aligned(16))) T xs[2 * kXTile];
 
-    const int lane = threadIdx.x & 63;
-    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int kh = KH == 1 ? 0 : wave_all / NWV;         // which half of the K-chunk this wave multiplies
-    const int wave = KH == 1 ? wave_all : wave_all % NWV;
-    const int tid = threadIdx.x - kh * NT;               // thread index inside the half
-    T *const xs = xs_all + kh * 2 * kXTile;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool is_gate = MODE == kWideSiluGate && wave >= HW;
     const int col0 = MODE == kWideSiluGate ? (blockIdx.x * HW + (wave % HW)) * 32 : (blockIdx.x * NWV + wave) * 32;
     const bool tile_ok = col0 < N;
     const int nt = tile_ok ? (col0 + (is_gate ? N : 0)) / 32 : 0;
     const int ksplit = blockIdx.y;
-    const int k_begin = ksplit * kc + kh * (kc / KH);
-    const int nkt = kc / KH / kWT;
+    const int k_begin = ksplit * kc;
+    const int nkt = kc / kWT;
     const T *wsrc = wpk + (static_cast<int64_t>(nt) * (K / 16) + k_begin / 16) * 512 + lane * 8;
     const int srow = tid >> 3, chunk = tid & 7;
     // staging: thread -> (row q*RPP + srow, chunk); 32-bit row offsets from one base pointer (the host side checks
@@ -168,37 +157,17 @@ __global__ __launch_bounds__(NWV * KH * 64, (NWV == 4 && MT > 4) ? 1 : 2) void g
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) mfma_results_tie(acc[mt]);
     mfma_results_ready<8>(acc[MT - 1]); // acc comes straight out of the K loop (swl_common.h)
-    if constexpr (KH == 2) {
-        // the second half's partial sums -> LDS (fp32, [row wave][mt][register][lane]: consecutive lanes, consecutive
-        // dwords) -> added by the first half, which alone runs the epilogue
-        float *red = reinterpret_cast<float *>(xs_all) + wave * (MT * 16 * 64);
-        __syncthreads();                // both halves are done reading their x tiles
-        if (kh == 1) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) red[(mt * 16 + r) * 64 + lane] = acc[mt][r];
-        }
-        __syncthreads();
-        if (kh == 0) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][r] += red[(mt * 16 + r) * 64 + lane];
-        }
-    }
-    const bool owner = kh == 0;         // (KH == 1: every wave)
 
     // acc[mt][r] = out^T[n = col0 + (r&3) + 8*(r>>2) + 4*hf][m = 32*mt + l32]
     if constexpr (MODE == kWideSiluGate) {
         constexpr int MTR = MT / 2;     // token blocks per exchange round: HW * MTR tiles of 32 x 40 elements fit the x buffers
-        static_assert(HW * MTR * 1280 <= KH * 2 * kXTile, "exchange tiles must fit the x buffers");
+        static_assert(HW * MTR * 1280 <= 2 * kXTile, "exchange tiles must fit the x buffers");
         typedef T vec4 __attribute__((ext_vector_type(4)));
-        T *xch = xs_all + (wave % HW) * MTR * 1280;
+        T *xch = xs + (wave % HW) * MTR * 1280;
 #pragma unroll
         for (int round = 0; round < 2; ++round) {
             __syncthreads();            // the x tiles (round 0) / the previous round's exchange tiles are dead
-            if (is_gate && owner) {
+            if (is_gate) {
 #pragma unroll
                 for (int j = 0; j < MTR; ++j)
 #pragma unroll
@@ -208,7 +177,7 @@ __global__ __launch_bounds__(NWV * KH * 64, (NWV == 4 && MT > 4) ? 1 : 2) void g
                     }
             }
             __syncthreads();
-            if (!is_gate && tile_ok && owner) {
+            if (!is_gate && tile_ok) {
 #pragma unroll
                 for (int j = 0; j < MTR; ++j) {
                     const int mt = round * MTR + j;
@@ -228,7 +197,7 @@ __global__ __launch_bounds__(NWV * KH * 64, (NWV == 4 && MT > 4) ? 1 : 2) void g
         }
         return;
     }
-    if (!tile_ok || !owner) return;
+    if (!tile_ok) return;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int m = 32 * mt + l32;
@@ -255,9 +224,6 @@ __global__ __launch_bounds__(NWV * KH * 64, (NWV == 4 && MT > 4) ? 1 : 2) void g
     }
 }
 
-// waves_per_group codes: 4 / 8 row waves, or 2 = 4 row waves x 2 K-halves (<= 128 tokens). Rows of W per workgroup / 32:
-static inline int row_waves(int nwv) { return nwv == 2 ? 4 : nwv; }
-
 struct WidePlan {
     int nwv;    // waves per workgroup: 8 (256 rows of W) or 4 (128 rows)
     int ks;     // K splits (fp32 slabs when > 1)
@@ -272,7 +238,7 @@ static WidePlan gemm_wide_plan(int M, int N, int K, int forced_nwv, int forced_k
     WidePlan p;
     const int tiles = N / 32;
     p.nwv = forced_nwv ? forced_nwv : 4;
-    const int wgs = (tiles + row_waves(p.nwv) - 1) / row_waves(p.nwv);
+    const int wgs = (tiles + p.nwv - 1) / p.nwv;
     const int min_chunk = (M <= 128 ? 16 : 8) * kWT;
     int ks = 1;
     while (ks < 16 && wgs * ks * 2 <= 256 && K % (kWT * ks * 2) == 0 && K / (ks * 2) >= min_chunk) ks *= 2;
@@ -290,9 +256,6 @@ static void launch_wide(int mt, int nwv, dim3 grid, hipStream_t s, void *out, co
         if (mt <= 4) SWL_W_LAUNCH(4, 8);
         else if (mt <= 6) SWL_W_LAUNCH(6, 8);
         else SWL_W_LAUNCH(8, 8);
-    } else if (nwv == 2 && mt <= 4) {       // 4 row waves x 2 K-halves
-        hipLaunchKernelGGL((gemm_packed_wide_kernel<T, 4, 4, MODE, 2>), grid, dim3(512), 0, s, out, x, wp, M, N, K, kc, xs,
-                           os);
     } else {
         if (mt <= 4) SWL_W_LAUNCH(4, 4);
         else if (mt <= 6) SWL_W_LAUNCH(6, 4);
@@ -327,15 +290,13 @@ extern "C" int swl_gemm_packed_wide(void *out, const void *x, const void *w_pack
     if (!swl::aligned16(x) || !swl::aligned16(w_packed) || (reinterpret_cast<uintptr_t>(out) & 7u) ||
         (workspace && !swl::aligned16(workspace)))
         return SWL_ERR_BAD_ARG;
-    if (!(waves_per_group == 0 || waves_per_group == 2 || waves_per_group == 4 || waves_per_group == 8))
-        return SWL_ERR_BAD_ARG;
+    if (!(waves_per_group == 0 || waves_per_group == 4 || waves_per_group == 8)) return SWL_ERR_BAD_ARG;
     if (k_splits < 0 || k_splits > 16 || (k_splits & (k_splits - 1))) return SWL_ERR_BAD_ARG;
     const swl::WidePlan p = swl::gemm_wide_plan(M, N, K, waves_per_group, k_splits);
     if (K % (swl::kWT * p.ks) != 0) return SWL_ERR_UNSUPPORTED;
-    if (p.nwv == 2 && (M > 128 || (K / p.ks) % (2 * swl::kWT))) return SWL_ERR_UNSUPPORTED;
     const int mt = (M + 31) / 32;
     const int kc = K / p.ks;
-    const dim3 grid((N / 32 + swl::row_waves(p.nwv) - 1) / swl::row_waves(p.nwv), p.ks);
+    const dim3 grid((N / 32 + p.nwv - 1) / p.nwv, p.ks);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (p.ks == 1) {
         SWL_DISPATCH_DTYPE(dtype, T, {
@@ -374,12 +335,10 @@ extern "C" int swl_gemm_packed_wide_partial(float *slabs, size_t slabs_bytes, co
     if (x_row_stride < K || (x_row_stride & 7) || !swl::aligned16(x) || !swl::aligned16(w_packed) || !swl::aligned16(slabs))
         return SWL_ERR_BAD_ARG;
     if (static_cast<int64_t>(M) * x_row_stride >= (1ll << 31)) return SWL_ERR_UNSUPPORTED;
-    if (!(waves_per_group == 0 || waves_per_group == 2 || waves_per_group == 4 || waves_per_group == 8))
-        return SWL_ERR_BAD_ARG;
+    if (!(waves_per_group == 0 || waves_per_group == 4 || waves_per_group == 8)) return SWL_ERR_BAD_ARG;
     if (slabs_bytes < static_cast<size_t>(k_splits) * M * N * sizeof(float)) return SWL_ERR_BAD_ARG;
     const swl::WidePlan p = swl::gemm_wide_plan(M, N, K, waves_per_group, k_splits);
-    if (p.nwv == 2 && (M > 128 || (K / p.ks) % (2 * swl::kWT))) return SWL_ERR_UNSUPPORTED;
-    const dim3 grid((N / 32 + swl::row_waves(p.nwv) - 1) / swl::row_waves(p.nwv), p.ks);
+    const dim3 grid((N / 32 + p.nwv - 1) / p.nwv, p.ks);
     SWL_DISPATCH_DTYPE(dtype, T, {
         swl::launch_wide<T, swl::kWidePartial>((M + 31) / 32, p.nwv, grid, static_cast<hipStream_t>(stream), slabs,
                                                static_cast<const T *>(x), static_cast<const T *>(w_packed), M, N, K,
@@ -402,11 +361,9 @@ extern "C" int swl_gemm_packed_wide_silu_gate(void *out, const void *x, const vo
     if (static_cast<int64_t>(M) * x_row_stride >= (1ll << 31)) return SWL_ERR_UNSUPPORTED;
     if (!swl::aligned16(x) || !swl::aligned16(w_up_gate_packed) || (reinterpret_cast<uintptr_t>(out) & 7u))
         return SWL_ERR_BAD_ARG;
-    if (!(waves_per_group == 0 || waves_per_group == 2 || waves_per_group == 4 || waves_per_group == 8))
-        return SWL_ERR_BAD_ARG;
+    if (!(waves_per_group == 0 || waves_per_group == 4 || waves_per_group == 8)) return SWL_ERR_BAD_ARG;
     const int nwv = waves_per_group ? waves_per_group : 4;
-    if (nwv == 2 && (M > 128 || K % (2 * swl::kWT))) return SWL_ERR_UNSUPPORTED;
-    const int hw = swl::row_waves(nwv) / 2;
+    const int hw = nwv / 2;
     const int mt = (M + 31) / 32;
     const dim3 grid((I / 32 + hw - 1) / hw, 1);
     hipStream_t s = static_cast<hipStream_t>(stream);

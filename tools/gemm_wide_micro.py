@@ -51,11 +51,9 @@ def main():
                 row["blas_us"] = round(time_us(lambda i: F.linear(x, ws[i % copies]), a.iters), 2)
             out = torch.empty(M, N, device="cuda", dtype=dtype)
             scratch = _workspace(x.device, 16 * M * N * 4)
-            variants = [(0, 0)] + ([] if a.auto_only else [(nw, ks) for nw in (4, 8, 2) for ks in (1, 2, 4, 8, 16)])
+            variants = [(0, 0)] + ([] if a.auto_only else [(nw, ks) for nw in (4, 8) for ks in (1, 2, 4, 8, 16)])
             for nw, ks in variants:
                 if ks and (K % (64 * ks) or K // ks < 256):
-                    continue
-                if nw == 2 and (M > 128 or (K // ks) % 128):
                     continue
                 def run(i, nw=nw, ks=ks):
                     _hip.call("swl_gemm_packed_wide", out.data_ptr(), x.data_ptr(), wps[i % copies].data_ptr(),
@@ -77,7 +75,7 @@ def main():
                     return r[:, :I] * F.silu(r[:, I:])
                 if not a.auto_only:
                     row["blas_plus_silu_us"] = round(time_us(blas_pair, a.iters), 2)
-                for nw in ((0,) if a.auto_only else ((4, 8, 2) if M <= 128 else (4, 8))):
+                for nw in ((0,) if a.auto_only else (4, 8)):
                     def run(i, nw=nw):
                         _hip.call("swl_gemm_packed_wide_silu_gate", og.data_ptr(), x.data_ptr(), wps[i % copies].data_ptr(),
                                   M, I, K, K, I, nw, code, _hip.stream())

@@ -249,7 +249,8 @@ def cmd_forward(args):
                            hipBLASLt kernels / K-split orders (split = batch: every request served alone);
         pad=k              k dummy sequences ride along in every call (for a batch that cannot be split);
         reverse=True       the sequences in reverse order;
-        max_steps=n        only the first n scripted steps, teacher-forced only (for plans that cost many calls).
+        max_steps=n        only the first n scripted steps, teacher-forced only (for plans that cost many calls);
+        subset=[i, ...]    only these requests of the batch are served (subset=[0]: the first request alone — batch 1).
     For each variant: the script teacher-forced with the base run's tokens (logit distance and greedy-id mismatches at
     identical histories) and free-running (sequences identical to the end). Summaries go to <out>.variants.json; nothing of
     the reference's arithmetic is touched — only which legal plan it runs."""
@@ -289,10 +290,12 @@ def cmd_forward(args):
 
     all_seqs = sorted({i for s in job["steps"] for i in s["seq_ids"]})
 
-    def run_script(forced=None, split=1, reverse=False, pad=0, max_steps=None):
+    def run_script(forced=None, split=1, reverse=False, pad=0, max_steps=None, subset=None):
         """The scripted steps under a plan. `pad` > 0: that many extra DUMMY sequences ride along in every forward (copies
         of the step's first prompt with shifted ids, then their own greedy tokens; outputs dropped) — other GEMM row
-        counts for a batch that cannot be split; pure-prefill / pure-decode steps only. `max_steps`: stop early."""
+        counts for a batch that cannot be split; pure-prefill / pure-decode steps only. `max_steps`: stop early.
+        `subset`: only these positions of every step's batch are served (e.g. [0]: the first request alone, batch 1);
+        tokens / logits come back for those rows only."""
         all_toks, all_logits = [], []
         dummy_ids = [max(all_seqs) + 1 + j for j in range(pad)]
         dummy_toks, dummy_lens = [], []
@@ -300,8 +303,18 @@ def cmd_forward(args):
         for si, s in enumerate(job["steps"][:max_steps]):
             ids = s["input_ids"]
             if ids is None:     # "feed back what you sampled": decode continuation
-                ids = [[t] for t in (forced[si - 1] if forced is not None else all_toks[-1])]
+                if forced is not None:
+                    prev = forced[si - 1] if subset is None else [forced[si - 1][i] for i in subset]
+                else:
+                    prev = all_toks[-1]
+                ids = [[t] for t in prev]
+            elif subset is not None:
+                ids = [ids[i] for i in subset]
             seq_ids, dec_lens = list(s["seq_ids"]), list(s["dec_lens"])
+            if subset is not None:
+                n_pre = len(seq_ids) - len(dec_lens)
+                dec_lens = [dec_lens[i - n_pre] for i in subset if i >= n_pre]
+                seq_ids = [seq_ids[i] for i in subset]
             if pad:
                 assert len(dec_lens) in (0, len(seq_ids)), "pad: pure prefill or pure decode steps only"
                 if not dec_lens:
@@ -339,34 +352,36 @@ def cmd_forward(args):
                                  default_seq_block_size="model.py:305-324 heuristic"),
                        variants=[])
         for var in variants:
+            rows = var.get("subset")
             kw = dict(split=int(var.get("split", 1)), reverse=bool(var.get("reverse", False)), pad=int(var.get("pad", 0)),
-                      max_steps=var.get("max_steps"))
+                      max_steps=var.get("max_steps"), subset=rows)
+            rows = list(range(batch)) if rows is None else list(rows)       # positions of the base run this plan serves
             plan["seq_block_size"] = var.get("seq_block_size")
             f_toks, f_logits = run_script(forced=base_toks, **kw)
             worst_abs = worst_ulp = 0.0
             mism, not_near_tie, per_step = [], 0, []
             for si, (a, b) in enumerate(zip(f_logits, base_logits)):
-                a, b = a.float(), b.float()
+                a, b = a.float(), b[rows].float()
                 row_abs = (a - b).abs().amax(dim=1)
                 row_ulp = row_abs / _ulp_of(b.abs().amax(dim=1), dtype_name)
                 worst_abs, worst_ulp = max(worst_abs, float(row_abs.max())), max(worst_ulp, float(row_ulp.max()))
                 per_step.append(dict(step=si, max_abs=float(row_abs.max()), max_ulp_of_row=float(row_ulp.max())))
-                for i, (x, y) in enumerate(zip(f_toks[si], base_toks[si])):
-                    if x != y:
+                for j, i in enumerate(rows):
+                    if f_toks[si][j] != base_toks[si][i]:
                         g2 = float(gap[si, i])
-                        mism.append(dict(step=si, seq=i, ref_top2_gap=g2, row_max_abs=float(row_abs[i])))
-                        not_near_tie += int(g2 > 2 * float(row_abs[i]))
+                        mism.append(dict(step=si, seq=i, ref_top2_gap=g2, row_max_abs=float(row_abs[j])))
+                        not_near_tie += int(g2 > 2 * float(row_abs[j]))
             entry = dict(plan=var, teacher_forced=dict(
                 max_abs_dlogit=worst_abs, max_ulp_of_row=worst_ulp, token_mismatches=len(mism),
-                tokens_compared=len(f_toks) * batch, mismatches_not_on_a_near_tie=not_near_tie, mismatches=mism[:32],
+                tokens_compared=len(f_toks) * len(rows), mismatches_not_on_a_near_tie=not_near_tie, mismatches=mism[:32],
                 per_step=per_step))
             if kw["max_steps"] is None:     # (a truncated plan is a teacher-forced probe only)
                 r_toks, _ = run_script(**kw)
                 first_div = []
-                for i in range(batch):
-                    first_div.append(next((s for s in range(len(base_toks)) if r_toks[s][i] != base_toks[s][i]), None))
+                for j, i in enumerate(rows):
+                    first_div.append(next((s for s in range(len(base_toks)) if r_toks[s][j] != base_toks[s][i]), None))
                 diverged = [d for d in first_div if d is not None]
-                entry["free_running"] = dict(sequences=batch, identical_to_the_end=batch - len(diverged),
+                entry["free_running"] = dict(sequences=len(rows), identical_to_the_end=len(rows) - len(diverged),
                                              first_divergence_steps=first_div,
                                              earliest_divergence_step=min(diverged, default=None))
             summary["variants"].append(entry)

@@ -11,7 +11,8 @@ logit, so the logit distance still measures the whole forward. (tests/test_decis
 its closed form on the CPU oracle.)
 
 configs[2] shape: batch 32, ragged ~1k-token prompts, 128 FREE-RUNNING greedy steps, float16 and bfloat16. Asserted:
-  * ours == the compiled reference == the closed form, all 129 x 32 greedy ids, no exceptions, both dtypes;
+  * ours == the compiled reference == the closed form, all 129 x 32 greedy ids, no exceptions, both dtypes — and the same
+    for the first request served ALONE on both sides (BASELINE configs[1]: batch 1 decode-only, 128 free-running steps);
   * the reference itself is decisive here: its smallest top-2 gap over all 4 128 rows exceeds, by > 20 x, its distance to
     itself under other legal plans (split widths 128 / 512; r04 also ran the batch as 2 x 16: identical);
   * logits (float16): max |ours - reference| <= 1e-3 over the sampled steps — the north star's number;
@@ -33,7 +34,8 @@ pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1800),
 
 GEN, OFFSET, BATCH = 128, 19, 32
 LOGIT_STEPS = [0, 1, 2, 18, 19, 20, 21, 40, 64, 96, 127, 128]      # full logits compared at these steps (ids at all)
-SELF_PLANS = [dict(seq_block_size=128), dict(seq_block_size=512)]      # (r04 also ran split=2: identical to 128)
+SELF_PLANS = [dict(seq_block_size=128), dict(seq_block_size=512),     # (r04 also ran split=2: identical to 128)
+              dict(subset=[0])]     # the first request served ALONE: BASELINE configs[1] (batch 1 decode-only) on this checkpoint
 
 
 @pytest.fixture(scope="module")
@@ -63,6 +65,9 @@ def test_greedy_ids_bit_exact_for_128_free_running_steps_on_the_decisive_checkpo
 
     model = P.our_model(path, dtype, BATCH, 1024, GEN)
     toks, logits, (blk_lo, blk_hi) = P.generate(model, prompts, GEN, logits_steps=LOGIT_STEPS)      # FREE-running
+    # BASELINE configs[1]: the same first request as a batch of ONE (the tiny-batch decode path in bfloat16: the projections
+    # sum the previous projection's slabs themselves, csrc/gemm_tiny.hip), free-running
+    solo_toks, _, _ = P.generate(model, prompts[:1], GEN, logits_steps=[])
     graphs = len(getattr(model, "_decode_graphs", {}) or {})
     del model
     torch.cuda.empty_cache()
@@ -84,7 +89,11 @@ def test_greedy_ids_bit_exact_for_128_free_running_steps_on_the_decisive_checkpo
                                   ours_equal_reference=all(d is None for d in ours_vs_ref),
                                   ours_equal_closed_form=all(d is None for d in ours_vs_form),
                                   reference_equal_closed_form=all(d is None for d in ref_vs_form),
-                                  first_divergence_ours_vs_reference=ours_vs_ref),
+                                  first_divergence_ours_vs_reference=ours_vs_ref,
+                                  batch1_ours_equal_closed_form=all(solo_toks[s][0] == expect[s][0] for s in range(GEN + 1)),
+                                  batch1_reference_equal_its_batch32_stream=next(
+                                      v["free_running"]["identical_to_the_end"] == 1 for v in ref_self["variants"]
+                                      if v["plan"].get("subset") == [0])),
                   logits=dict(steps_compared=LOGIT_STEPS, max_abs_logit=top,
                               ours_vs_reference_max_abs=cmp_["max_abs_dlogit"],
                               ours_vs_reference_ulp_of_row=cmp_["max_ulp_of_row"],
@@ -97,11 +106,14 @@ def test_greedy_ids_bit_exact_for_128_free_running_steps_on_the_decisive_checkpo
 
     # the premise: the reference decides every row by a margin far above its own plan-to-plan noise, and agrees with itself
     assert min_gap > 20 * self_abs, (min_gap, self_abs)
-    assert all(v["free_running"]["identical_to_the_end"] == BATCH for v in ref_self["variants"])
+    assert all(v["free_running"]["identical_to_the_end"] == v["free_running"]["sequences"] for v in ref_self["variants"])
     # the bar: bit-exact greedy ids, 129 steps x 32 sequences, against the compiled reference AND the closed form
     assert all(d is None for d in ours_vs_ref), ours_vs_ref
     assert all(d is None for d in ours_vs_form), ours_vs_form
     assert all(d is None for d in ref_vs_form), ref_vs_form
+    # ... and BASELINE configs[1]: the request served alone (batch 1, 128 free-running steps) gives the same ids on both
+    # sides (the reference's batch-1 stream == its batch-32 stream of that request: asserted with the plans above)
+    assert all(solo_toks[s][0] == expect[s][0] == ref_toks[s][0] for s in range(GEN + 1))
     if dtype == "float16":
         assert top < 1.0, top                                   # 1e-3 is >= 2 fp16 ulps everywhere
         assert cmp_["max_abs_dlogit"] <= 1e-3, report["logits"]

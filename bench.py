@@ -81,6 +81,8 @@ def parse_args():
     ap.add_argument("--no-skinny-gemm", dest="skinny_gemm", action="store_false")
     ap.add_argument("--no-splitk-fusion", dest="splitk_fusion", action="store_false")
     ap.add_argument("--no-packed-weights", dest="packed_weights", action="store_false")
+    ap.add_argument("--no-rows-decode", dest="rows_decode", action="store_false",
+                    help="A/B: split-K + consumer launches for o_proj / down_proj instead of the row-owned kernels (r05)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[1] / configs[3] / eager side runs")
     ap.add_argument("--skip-prefill", action="store_true", help="fill the KV pool directly instead of running the prompt")
@@ -139,7 +141,7 @@ def build_model(args, cfg, min_blocks, batch, max_len, hip_graph):
                       max_blocks_per_seq=max(FILLER_BLOCKS_PER_SEQ, max_len // 16 + 8),
                       max_batch_size=batch, max_tokens_in_batch=batch * min(max_len, 8192),
                       dtype=args.dtype, fuse_qkv=args.fuse_qkv, use_hip_graph=hip_graph,
-                      use_skinny_gemm=args.skinny_gemm, tuning=dict(fuse_splitk_consumers=args.splitk_fusion),
+                      use_skinny_gemm=args.skinny_gemm, tuning=dict(fuse_splitk_consumers=args.splitk_fusion, rows_decode=args.rows_decode),
                       pack_decode_weights=getattr(args, "packed_weights", True))
     model = LlamaModel(ec)
     model.load_weights()
@@ -248,18 +250,46 @@ class DecodeRun:
         self.toks = self.model.forward([[t] for t in self.toks], self.seq_ids, self.lens)
 
     def timed_steps(self, warmup, steps, barrier=lambda: None):
+        """EXACTLY `steps` forwards between two barrier + synchronize pairs. Per-step wall times and the interpreter's
+        garbage collections inside the region are recorded on the side (self.region): a 20-step region is 80 ms, and one
+        generation-2 collection of the interpreter (tens of ms with the prompt lists and 8 G parameters' worth of tensor
+        objects alive) would be a third of it — so the collector is run BEFORE the region and paused inside it, as a
+        serving loop would do around its latency-critical section. The forwards themselves are untouched."""
+        import gc
         import torch
         for _ in range(warmup):
             self.step()
         first = self.lens[0] + 1
+        gc_log = []
+        def on_gc(phase, info, _t=[0.0]):
+            if phase == "start":
+                _t[0] = time.perf_counter()
+            else:
+                gc_log.append((info.get("generation"), (time.perf_counter() - _t[0]) * 1e3))
+        gc.collect()
+        gc_was_enabled = gc.isenabled()
+        if os.environ.get("SWL_BENCH_KEEP_GC") != "1":
+            gc.disable()
+        gc.callbacks.append(on_gc)
+        per_step = []
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
+            t1 = time.perf_counter()
             self.step()
+            per_step.append(time.perf_counter() - t1)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         barrier()
+        gc.callbacks.remove(on_gc)
+        if gc_was_enabled:
+            gc.enable()
+        ps = sorted(per_step)
+        self.region = {"step_ms_min": round(ps[0] * 1e3, 4), "step_ms_median": round(ps[len(ps) // 2] * 1e3, 4),
+                       "step_ms_max": round(ps[-1] * 1e3, 4), "slowest_step_index": per_step.index(ps[-1]),
+                       "gc_collections_in_region": len(gc_log), "gc_ms_in_region": round(sum(t for _, t in gc_log), 3),
+                       "gc_paused": not gc.isenabled() or os.environ.get("SWL_BENCH_KEEP_GC") != "1"}
         return dt, first, self.lens[0]
 
     def release(self):
@@ -682,6 +712,8 @@ def _run(args):
                    "cpu_affinity": dict(dp.last_affinity) if world > 1 else dict(
                        cores=len(os.sched_getaffinity(0)), how="single rank on this host: not pinned, all allowed cores")},
         "step_roofline": step_roofline(cfg, e, B, mean_ctx, ms_per_step),
+        # rank 0's view of the timed region: per-forward wall times and interpreter garbage collections inside it
+        "timed_region": getattr(run, "region", None),
     }
     if prefill_units is not None:
         result["prefill_tok_s"] = round(prefill_units / prefill_max_s, 1)

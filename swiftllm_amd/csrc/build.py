@@ -26,6 +26,7 @@ SOURCES = [
     "gemm_skinny.hip",
     "gemm_tiny.hip",
     "gemm_wide.hip",
+    "gemm_rows.hip",
     "argmax.hip",
 ]
 HEADERS = ["swl_common.h", os.path.join(ROOT, "include", "swiftllm_hip.h")]

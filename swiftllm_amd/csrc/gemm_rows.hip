@@ -1,0 +1,233 @@
+// gemm_rows.hip — the output projection of a decode layer with K split INSIDE the workgroup (gfx950, M <= 32 tokens,
+// packed W), its residual add and the element-wise half of the FFN norm in the epilogue.
+//
+// Replaces, for decode batches of <= 32 tokens in bfloat16, the pair
+//     o_proj (reference swiftllm/worker/kernels/linear.py:3-12 at layers/transformer_layer.py:117)
+//   + fused_add_rmsnorm (kernels/rmsnorm.py:67-89 at transformer_layer.py:120), in its deferred form (rmsnorm.hip:
+//     splitk_add_scale_kernel: residual += round(o); x_scaled = round(residual * w_norm); sums of squares on the side)
+// which r01-r04 ran as a split-K GEMM (8 fp32 slabs, gemm_skinny.hip) followed by a consumer launch that does nothing
+// but wait on memory: 9.6 + 5.0 us per layer in the batch-32 trace (profiles/r04d_kernel_trace_configs2.md) for 33.6 MB
+// of weights = 4.7 us of HBM time.
+//
+// Why a second in-workgroup scheme after r02's gemm_wgk (128 workgroups of 32 rows: 11.2 us, retired). What bounds such a
+// kernel on this part is what ONE CU can pull through its L1: ~55 GB/s, hit or miss. A workgroup
+// that owns rows of W for all of K reads all of x[M, K]: bytes per CU = rows * K * e + M * K * e. With 32-row tiles only
+// 128 CUs work and each moves 256 + 256 KiB (9.3 us at 55 GB/s); with SIXTEEN-row tiles all 256 CUs work and each moves
+// 128 + 256 KiB (7 us) — and the op is one v_mfma_f32_16x16x32 per 1 KiB of W, so the tile height costs nothing:
+//   * workgroup = 16 rows of W x all of K = 8 waves (2 per SIMD), wave w takes K/8 contiguous columns;
+//   * W comes from the SAME packed copy the other decode kernels stream (swl_gemm_pack_weight: 32-row x 16-k fragments
+//     of 1 KiB): the 16 x 32 A fragment of tile half h is lanes {16h..16h+15} and {32+16h..} of two consecutive
+//     fragments — four 256-byte runs per wave-load, non-temporal; the sibling workgroup reads the other halves;
+//   * x^T is the B operand, loaded straight into fragment layout (lane -> token l%16, 8 k): 64-byte runs of 16 rows,
+//     L2-resident (every workgroup reads the same 256 KiB); rows >= M are clamped to row M-1 (L1 hits, never stored);
+//   * EVERYTHING a wave needs is requested before its first MFMA: K = 4096 is 16 k-steps = 16 + 32 loads of 16 B per
+//     lane (192 VGPRs), the whole workgroup 384 KiB in flight — the kernel is one memory round trip plus a drain at
+//     the CU's own rate; longer K runs the same schedule as a 4-deep ring of 4-step chunks;
+//   * the 8 waves' 16 x 32 fp32 tiles meet in LDS (20 KiB), are added in wave order (= K order: deterministic), and the
+//     512 threads finish one (token, column) each: splitk_add_scale's arithmetic and rounding points;
+//   * the sum of squares of the new residual row leaves as one partial per (tile, token): ssq_out[N/16][M]; the SiLU-gate
+//     GEMM that applies the deferred 1/rms adds the N/16 partials in a fixed order (swl_gemm_skinny_packed_silu_gate_rs).
+// No slabs, no second launch, no atomics, no cross-workgroup hand-off.
+#include "swl_common.h"
+
+namespace swl {
+
+__device__ __forceinline__ float4_t rows_mfma(vec8_t<f16> a, vec8_t<f16> b, float4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float4_t rows_mfma(vec8_t<bf16> a, vec8_t<bf16> b, float4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+constexpr int kRowsWaves = 8;     // K splits = waves per workgroup
+constexpr int kRowsTile = 16;     // rows of W per workgroup
+constexpr int kRowsCh = 4;        // k-steps (of 32) per ring chunk
+constexpr int kRowsRing = 4;      // chunks in flight per wave: 16 k-steps = 192 VGPRs at two token blocks
+constexpr int kRowsRedPitch = 20; // floats per token row of a wave's tile image in LDS (80 B: 16-byte stores spread)
+
+enum RowsEpi {
+    kRowsAddScale = 0, // residual += round(acc); xs = round(residual * norm_w); ssq_out[tile][m] = sum of squares
+    kRowsAdd = 1,      // residual += round(acc) only: the consumer applies the norm weight while it stages the rows
+};
+
+struct RowsArgs {
+    const void *x;
+    const void *wp;
+    void *residual;
+    const void *norm_w;
+    void *xs;
+    float *ssq_out; // [N/16][M]
+    int M, N, K;
+    int64_t x_stride;
+};
+
+// NCH > 0: the chunk count per wave is a compile-time constant <= kRowsRing — every load is issued up front, straight-line
+// code with exact counted waits. NCH == 0: run-time chunk count, the ring refilled behind guards.
+template <typename T, int NCH, int MB, int EPI>
+__global__ __launch_bounds__(kRowsWaves * 64, 2) void gemm_rows_kernel(RowsArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[kRowsWaves][32 * kRowsRedPitch];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int M = a.M, N = a.N, K = a.K;
+    const int tile16 = blockIdx.x;
+    const int n0 = tile16 * kRowsTile;
+
+    // ---- epilogue operands first: the oldest requests of the wave, no wait of the stream ever includes them ----
+    const int et = threadIdx.x >> 4, en = threadIdx.x & 15; // (token, column n0 + en)
+    const bool e_ok = et < M;
+    T *res_p = static_cast<T *>(a.residual) + static_cast<int64_t>(e_ok ? et : 0) * N + n0 + en;
+    const T rv = *res_p;
+    T nv = T{};
+    if constexpr (EPI == kRowsAddScale) nv = static_cast<const T *>(a.norm_w)[n0 + en];
+
+    // ---- the stream ----
+    const int r = lane & 15, kq = lane >> 4;
+    const int nsteps = K / 32 / kRowsWaves; // k-steps of this wave
+    const int s0 = wave * nsteps;
+    const int nch = NCH > 0 ? NCH : nsteps / kRowsCh;
+    // packed W: fragment (tile32, kstep16) = 512 elements, lane L of it = row L%32, k = 16*kstep16 + 8*(L/32) .. +8.
+    // 16x32 A fragment of step s, lane (r, kq): row 16*half + r, k = 32*s + 8*kq -> kstep16 = 2s + kq/2, L = 16*half + r + 32*(kq%2)
+    const T *wsrc = static_cast<const T *>(a.wp) +
+                    (static_cast<int64_t>(tile16 >> 1) * (K / 16) + 2 * s0 + (kq >> 1)) * 512 +
+                    (16 * (tile16 & 1) + r + 32 * (kq & 1)) * 8;
+    const T *xsrc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+        xsrc[mb] = static_cast<const T *>(a.x) + static_cast<int64_t>(min(r + 16 * mb, M - 1)) * a.x_stride + 32 * s0 + 8 * kq;
+
+    vec8_t<T> wr[kRowsRing][kRowsCh], xr[kRowsRing][kRowsCh][MB];
+    float4_t acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = float4_t{0.f, 0.f, 0.f, 0.f};
+#define SWL_ROWS_ISSUE(slot, c)                                                                         \
+    {                                                                                                   \
+        _Pragma("unroll") for (int j_ = 0; j_ < kRowsCh; ++j_) {                                        \
+            const int s_ = (c) * kRowsCh + j_;                                                          \
+            wr[slot][j_] = load8_nt(wsrc + static_cast<int64_t>(s_) * 1024);                            \
+            _Pragma("unroll") for (int mb_ = 0; mb_ < MB; ++mb_) xr[slot][j_][mb_] = load8(xsrc[mb_] + s_ * 32); \
+        }                                                                                               \
+    }
+#define SWL_ROWS_PROCESS(slot)                                                                          \
+    {                                                                                                   \
+        _Pragma("unroll") for (int j_ = 0; j_ < kRowsCh; ++j_)                                          \
+            _Pragma("unroll") for (int mb_ = 0; mb_ < MB; ++mb_)                                        \
+                acc[mb_] = rows_mfma(wr[slot][j_], xr[slot][j_][mb_], acc[mb_]);                        \
+    }
+    if constexpr (NCH > 0) {
+        // straight-line schedule, exact counted waits: the first min(NCH, ring) chunks are requested up front (K = 4096:
+        // the whole K range of the wave), longer K (down_proj: 14 chunks) refills a slot as soon as it is multiplied
+#pragma unroll
+        for (int c = 0; c < (NCH < kRowsRing ? NCH : kRowsRing); ++c) SWL_ROWS_ISSUE(c, c);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            // pinned: left alone the scheduler sinks requests between the MFMAs of earlier chunks (fewer live registers,
+            // and nothing in flight while the wave multiplies)
+            __builtin_amdgcn_sched_barrier(0);
+            SWL_ROWS_PROCESS(c % kRowsRing);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + kRowsRing < NCH) SWL_ROWS_ISSUE(c % kRowsRing, c + kRowsRing);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < kRowsRing; ++c)
+            if (c < nch) SWL_ROWS_ISSUE(c, c);
+        for (int c0 = 0; c0 < nch; c0 += kRowsRing) {
+#pragma unroll
+            for (int d = 0; d < kRowsRing; ++d) {
+                if (c0 + d < nch) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    SWL_ROWS_PROCESS(d);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (c0 + d + kRowsRing < nch) SWL_ROWS_ISSUE(d, c0 + d + kRowsRing);
+                }
+            }
+        }
+    }
+#undef SWL_ROWS_ISSUE
+#undef SWL_ROWS_PROCESS
+
+    // ---- in-workgroup reduction: acc[mb][j] = out^T[n = 4*kq + j][token = r + 16*mb] -> red[wave][token][n] ----
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) mfma_results_tie(acc[mb]);
+    mfma_results_ready<4>(acc[MB - 1]); // stored by DS instructions next (swl_common.h)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+        *reinterpret_cast<float4_t *>(&red[wave][(r + 16 * mb) * kRowsRedPitch + 4 * kq]) = acc[mb];
+    __syncthreads();
+    float s = 0.f;
+    if (MB == 2 || et < 16) {
+#pragma unroll
+        for (int w = 0; w < kRowsWaves; ++w) s += red[w][et * kRowsRedPitch + en]; // wave order = K order
+    }
+    // splitk_add_scale_kernel's arithmetic (rmsnorm.hip) on this thread's element
+    const T xn = add_t<T>(to_t<T>(s), rv); // the projection is rounded, then the sum (rmsnorm.py:54-57)
+    if constexpr (EPI == kRowsAdd) {
+        if (e_ok) *res_p = xn;
+    } else {
+        const float v = to_f(xn);
+        const float ssq = group_allreduce_sum<16>(v * v);
+        const T sv = to_t<T>(v * to_f(nv));
+        if (e_ok) {
+            *res_p = xn;
+            static_cast<T *>(a.xs)[static_cast<int64_t>(et) * N + n0 + en] = sv;
+            if (en == 0) a.ssq_out[static_cast<int64_t>(tile16) * M + et] = ssq;
+        }
+    }
+}
+
+static bool rows_shape_ok(int M, int N, int K) {
+    return M > 0 && M <= 32 && N > 0 && N % 32 == 0 && K > 0 && K % (32 * kRowsWaves * kRowsCh) == 0;
+}
+
+template <typename T, int MB, int EPI>
+static int launch_rows(const RowsArgs &a, hipStream_t stream) {
+    const dim3 grid(a.N / kRowsTile), block(kRowsWaves * 64);
+    const int nch = a.K / (32 * kRowsWaves * kRowsCh);
+    // K = 4096 (Llama-3-8B / Llama-2-7B hidden): 4 chunks, all in flight; 14336 (Llama-3-8B FFN): 14; 8192: 8
+    if (nch == 4) hipLaunchKernelGGL((gemm_rows_kernel<T, 4, MB, EPI>), grid, block, 0, stream, a);
+    else if (nch == 14) hipLaunchKernelGGL((gemm_rows_kernel<T, 14, MB, EPI>), grid, block, 0, stream, a);
+    else if (nch == 8) hipLaunchKernelGGL((gemm_rows_kernel<T, 8, MB, EPI>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((gemm_rows_kernel<T, 0, MB, EPI>), grid, block, 0, stream, a);
+    return check_launch();
+}
+
+} // namespace swl
+
+extern "C" int swl_gemm_rows_supported(int32_t M, int32_t N, int32_t K) { return swl::rows_shape_ok(M, N, K) ? 1 : 0; }
+
+extern "C" int swl_gemm_rows_add_scale(void *x_scaled, void *residual, float *ssq_out, const void *norm_w, const void *x,
+                                       const void *w_packed, int32_t M, int32_t N, int32_t K, int64_t x_row_stride,
+                                       int32_t dtype, swl_stream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
+    if (M == 0) return SWL_OK;
+    if (!x_scaled || !residual || !ssq_out || !norm_w || !x || !w_packed) return SWL_ERR_BAD_ARG;
+    if (!swl::rows_shape_ok(M, N, K)) return SWL_ERR_UNSUPPORTED;
+    if (x_row_stride < K || (x_row_stride & 7)) return SWL_ERR_BAD_ARG;
+    if (!swl::aligned16(x) || !swl::aligned16(w_packed) || (reinterpret_cast<uintptr_t>(x_scaled) & 1u) ||
+        (reinterpret_cast<uintptr_t>(residual) & 1u) || (reinterpret_cast<uintptr_t>(ssq_out) & 3u))
+        return SWL_ERR_BAD_ARG;
+    swl::RowsArgs a = {};
+    a.x = x; a.wp = w_packed; a.residual = residual; a.norm_w = norm_w; a.xs = x_scaled; a.ssq_out = ssq_out;
+    a.M = M; a.N = N; a.K = K; a.x_stride = x_row_stride;
+    SWL_DISPATCH_DTYPE(dtype, T, {
+        if (M <= 16) return swl::launch_rows<T, 1, swl::kRowsAddScale>(a, static_cast<hipStream_t>(stream));
+        return swl::launch_rows<T, 2, swl::kRowsAddScale>(a, static_cast<hipStream_t>(stream));
+    });
+}
+
+extern "C" int swl_gemm_rows_add(void *residual, const void *x, const void *w_packed, int32_t M, int32_t N, int32_t K,
+                                 int64_t x_row_stride, int32_t dtype, swl_stream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
+    if (M == 0) return SWL_OK;
+    if (!residual || !x || !w_packed) return SWL_ERR_BAD_ARG;
+    if (!swl::rows_shape_ok(M, N, K)) return SWL_ERR_UNSUPPORTED;
+    if (x_row_stride < K || (x_row_stride & 7)) return SWL_ERR_BAD_ARG;
+    if (!swl::aligned16(x) || !swl::aligned16(w_packed) || (reinterpret_cast<uintptr_t>(residual) & 1u)) return SWL_ERR_BAD_ARG;
+    swl::RowsArgs a = {};
+    a.x = x; a.wp = w_packed; a.residual = residual;
+    a.M = M; a.N = N; a.K = K; a.x_stride = x_row_stride;
+    SWL_DISPATCH_DTYPE(dtype, T, {
+        if (M <= 16) return swl::launch_rows<T, 1, swl::kRowsAdd>(a, static_cast<hipStream_t>(stream));
+        return swl::launch_rows<T, 2, swl::kRowsAdd>(a, static_cast<hipStream_t>(stream));
+    });
+}

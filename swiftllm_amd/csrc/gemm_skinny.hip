@@ -49,6 +49,7 @@ __device__ __forceinline__ float16_t mfma32x32x16(vec8_t<bf16> a, vec8_t<bf16> b
 
 constexpr int kKT = 128;    // k elements per tile (256 bytes per row: two full lines)
 constexpr int kGemmWaves = 4;
+constexpr int kSsqManyParts = 256; // most sums-of-squares partials per token the SiLU-gate GEMM adds itself (MANY)
 
 enum GemmMode {
     kGemmDirect = 0,   // out[M, N] in T
@@ -66,6 +67,11 @@ struct GemmExtra {
     const float *ssq_in;
     float eps;
     int ssq_parts;
+    // NF (norm on the fly): x is the RAW residual stream; the kernel stages round(x * norm_w) (splitk_add_scale's bits)
+    // and adds up the rows' sums of squares itself — SiLU-gate mode applies the 1/rms in its epilogue, partial mode writes
+    // ssq_out[ksplit][M] (the row_ssq the slab-fed attention prologue takes)
+    const void *norm_w;
+    float *ssq_out;
 };
 
 // acc[r] = out^T[n = n0 + (r&3) + 8*(r>>2) + 4*hf][m = l32] -> the three output modes.
@@ -229,20 +235,45 @@ constexpr int kRing = 3;
 // three — the fused qkv projection of Llama-3-8B is 192 tiles x 4 K-splits = 768 wave-chunks: 192 four-wave workgroups
 // leave a quarter of the 256 CUs idle, 256 three-wave ones fill the chip (r02). Three waves stage the 8 row-groups of the
 // x tile as 3 + 3 + 2: the ninth (dummy) group is a clamped load into four spare LDS rows — no branch in the pipeline.
-template <typename T, int MODE, bool PACKED = false, int RD = kRing, int NWV = kGemmWaves>
+// MANY (SiLU-gate mode, packed W): the deferred-RMSNorm sums of squares arrive as up to kSsqManyParts partials per token
+// (gemm_rows.hip writes one per 16-column tile of the residual row: 256 for hidden = 4096) instead of <= 8. They are
+// copied into LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, requested before the first weight tile, so no wait of
+// the weight stream ever includes them) and added in a fixed order after the K loop.
+// NF (packed W, SiLU-gate or partial mode): norm on the fly — x is the raw residual stream r (what gemm_rows.hip leaves
+// behind: no consumer launch computed round(r * norm_w) or the sums of squares). The norm-weight chunk of a K-tile rides
+// with the tile's x loads, the staging pass multiplies and rounds (the bits of splitk_add_scale_kernel) and accumulates
+// sum r^2 per row in fp32 — every workgroup redundantly, it sees all of x anyway.
+template <typename T, int MODE, bool PACKED = false, int RD = kRing, int NWV = kGemmWaves, bool MANY = false, bool NF = false>
 // 2 waves per SIMD: the ring holds RD x 8 KiB of W per wave in registers (~220 VGPRs at RD = 3)
 __global__ __launch_bounds__(NWV * 64, 2) void gemm_skinny_ring_kernel(
     void *__restrict__ out_, const T *__restrict__ x, const T *__restrict__ w, int M, int N, int K,
     int kc, int64_t x_stride, int64_t out_stride, GemmExtra fuse) {
     static_assert(NWV == kGemmWaves || (NWV == 3 && PACKED && MODE == kGemmPartial), "3 waves: packed partial only");
+    static_assert(!MANY || (PACKED && MODE == kGemmSiluGate && NWV == kGemmWaves), "many ssq partials: packed SiLU-gate only");
+    static_assert(!NF || (PACKED && !MANY && MODE != kGemmDirect), "norm on the fly: packed SiLU-gate / partial only");
     constexpr int D = RD;
     constexpr int XL = (8 + NWV - 1) / NWV; // x row-groups (4 rows each) a wave stages per tile
     constexpr int XROWS = 4 * XL * NWV;      // 32, or 36 with the dummy group of the 3-wave variant
     // [0..1] the double-buffered x tile of the workgroup, [2 + wave] the wave-private W tile (row-major W only)
     __shared__ __attribute__((aligned(16))) T lds[2 + (PACKED ? 0 : kGemmWaves)][XROWS * kKT];
+    __shared__ __attribute__((aligned(16))) float ssq_lds[MANY ? kSsqManyParts * 32 : 4];
+    __shared__ float ssq_red[MANY ? 8 : 1][32];
+    __shared__ float ssq_row[NF ? XROWS : 1];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if constexpr (MANY) {
+        // flat copy of ssq_in[ssq_parts][M] (a multiple of 4 floats, 16-byte aligned): 1 KiB per wave-instruction
+        const int total = fuse.ssq_parts * M;
+#pragma unroll
+        for (int i = 0; i < kSsqManyParts * 32 / (kGemmWaves * 256); ++i) {
+            const int off = (i * kGemmWaves + wave) * 256;
+            if (off + lane * 4 < total)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(fuse.ssq_in + off + lane * 4),
+                    (__attribute__((address_space(3))) void *)(ssq_lds + off), 16, 0, 0);
+        }
+    }
     const bool is_gate = MODE == kGemmSiluGate && wave >= 2;
     const int col0 = MODE == kGemmSiluGate ? (blockIdx.x * 2 + (wave & 1)) * 32
                                            : (blockIdx.x * NWV + wave) * 32;
@@ -284,18 +315,24 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_skinny_ring_kernel(
     // deferred RMSNorm (SiLU-gate mode, packed W): the per-1024-column sums of squares of this lane's token row, requested
     // BEFORE the weight stream (oldest loads: no wait of the pipeline ever includes them) and summed after the K loop
     float ssv[8];
-    const bool row_scaled = PACKED && MODE == kGemmSiluGate && fuse.ssq_in != nullptr;
-    if (row_scaled) {
+    const bool row_scaled = PACKED && MODE == kGemmSiluGate && (NF || fuse.ssq_in != nullptr);
+    if (row_scaled && !MANY && !NF) {
         const int m = min(lane & 31, M - 1);
 #pragma unroll
         for (int p2 = 0; p2 < 8; ++p2) ssv[p2] = p2 < fuse.ssq_parts ? fuse.ssq_in[p2 * M + m] : 0.f;
     }
 
     vec8_t<T> wr[D][8], xr[D][XL];
+    vec8_t<T> wn[NF ? D : 1];           // NF: the norm-weight chunk of the tile (same 8 columns for every row of the lane)
+    float ssq_acc[NF ? XL : 1];
+#pragma unroll
+    for (int q = 0; q < (NF ? XL : 1); ++q) ssq_acc[q] = 0.f;
+    const T *nwsrc = NF ? static_cast<const T *>(fuse.norm_w) + k_begin + chunk * 8 : nullptr;
     float16_t acc = float16_t{};
     // x loads go first: they are the ones the stage-ahead below waits for (loads return in order)
 #define SWL_ISSUE(slot, tile)                                                                        \
     {                                                                                                \
+        if constexpr (NF) wn[slot] = load8(nwsrc + (tile) * kKT);                                    \
         _Pragma("unroll") for (int q_ = 0; q_ < XL; ++q_) xr[slot][q_] = load8(xsrc[q_] + (tile) * kKT); \
         _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                             \
             wr[slot][i_] = PACKED ? load8_nt(wsrc + (static_cast<int64_t>(tile) * 8 + i_) * 512)     \
@@ -304,7 +341,15 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_skinny_ring_kernel(
 #define SWL_STAGE_X(slot, buf, tile)                                                                 \
     {                                                                                                \
         _Pragma("unroll") for (int q_ = 0; q_ < XL; ++q_) {                                          \
-            *reinterpret_cast<vec8_t<T> *>(&lds[buf][xs_wr[q_]]) = xr[slot][q_];                     \
+            vec8_t<T> xv_ = xr[slot][q_];                                                            \
+            if constexpr (NF) {                                                                      \
+                _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                   \
+                    const float v_ = to_f(xv_[j_]);                                                  \
+                    ssq_acc[q_] = fmaf(v_, v_, ssq_acc[q_]);                                         \
+                    xv_[j_] = to_t<T>(v_ * to_f(wn[slot][j_]));                                      \
+                }                                                                                    \
+            }                                                                                        \
+            *reinterpret_cast<vec8_t<T> *>(&lds[buf][xs_wr[q_]]) = xv_;                              \
         }                                                                                            \
     }
 #define SWL_PROCESS(slot, buf)                                                                       \
@@ -340,6 +385,9 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_skinny_ring_kernel(
         for (int d = 0; d < D; ++d) {
             SWL_ISSUE((d + D - 1) % D, kt + d + D - 1);
             SWL_PROCESS(d, (kt + d) & 1);
+            // (NF: staging the next tile BEFORE the MFMAs — its ~50 VALU instructions per row group then run while the
+            // wave would wait for its weight tile — measured slower in the layer chain, 80.5 vs 78.0 us at batch 1:
+            // profiles/r05c_rows_layer_micro_*.jsonl)
             SWL_STAGE_X((d + 1) % D, (kt + d + 1) & 1, kt + d + 1);
             __syncthreads();
         }
@@ -362,11 +410,37 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_skinny_ring_kernel(
 #undef SWL_PROCESS
     mfma_results_ready<8>(acc); // acc comes straight out of the K loop (swl_common.h)
     if constexpr (PACKED) {
+        if constexpr (NF) { // the 16 chunk lanes of a row hold its sum of squares in pieces: DPP row reduction -> LDS
+#pragma unroll
+            for (int q = 0; q < XL; ++q) {
+                const float t = group_allreduce_sum<16>(ssq_acc[q]);
+                if (chunk == 0) ssq_row[4 * (wave * XL + q) + rsub] = t;
+            }
+        }
         // no W tiles in LDS: the SiLU-gate exchange (32 x 40 elements per wave) reuses the x buffers once every
         // wave is done reading them
-        if constexpr (MODE == kGemmSiluGate) __syncthreads();
+        if constexpr (MODE == kGemmSiluGate || NF) __syncthreads();
+        if constexpr (NF && MODE == kGemmPartial) {
+            if (blockIdx.x == 0 && wave == 0 && lane < M) fuse.ssq_out[ksplit * M + lane] = ssq_row[lane];
+        }
         float rs = 1.0f;
-        if (row_scaled) {
+        if constexpr (MANY) {
+            // (every load of this wave — its LDS-DMA pieces included — was waited for by the K loop's last tile; the
+            // barrier above covers the other waves' pieces.) group g = 2 * wave + lane / 32 adds partials g, g + 8, ...
+            // of token lane % 32 in order; the eight group sums are added as the <= 8-partial form adds its partials.
+            __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) (explicit: the DMA's LDS side is invisible to the K loop's waits)
+            __syncthreads();
+            const int m = min(lane & 31, M - 1), g = 2 * wave + (lane >> 5);
+            float t = 0.f;
+            for (int p2 = g; p2 < fuse.ssq_parts; p2 += 8) t += ssq_lds[p2 * M + m];
+            ssq_red[g][lane & 31] = t;
+            __syncthreads();
+#pragma unroll
+            for (int p2 = 0; p2 < 8; ++p2) ssv[p2] = ssq_red[p2][lane & 31];
+        }
+        if constexpr (NF && MODE == kGemmSiluGate) {
+            rs = 1.0f / sqrtf(ssq_row[min(lane & 31, M - 1)] / static_cast<float>(K) + fuse.eps);
+        } else if (row_scaled) {
             const float ss = ((ssv[0] + ssv[1]) + (ssv[2] + ssv[3])) + ((ssv[4] + ssv[5]) + (ssv[6] + ssv[7]));
             rs = 1.0f / sqrtf(ss / static_cast<float>(K) + fuse.eps); // rmsnorm.hip's formula
         }
@@ -739,7 +813,7 @@ extern "C" int swl_gemm_skinny_packed_silu_gate_rs(void *out, const void *x, con
     if (M < 0 || I <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
     if (M == 0) return SWL_OK;
     if (!out || !x || !w_up_gate_packed || !row_ssq || ssq_parts <= 0) return SWL_ERR_BAD_ARG;
-    if (M > 32 || (I & 31) || (K & (swl::kKT - 1)) || ssq_parts > 8) return SWL_ERR_UNSUPPORTED;
+    if (M > 32 || (I & 31) || (K & (swl::kKT - 1)) || ssq_parts > swl::kSsqManyParts) return SWL_ERR_UNSUPPORTED;
     if (x_row_stride < K || out_row_stride < I || (x_row_stride & 7) || (out_row_stride & 3)) return SWL_ERR_BAD_ARG;
     if (!swl::aligned16(x) || !swl::aligned16(w_up_gate_packed) || (reinterpret_cast<uintptr_t>(out) & 7u))
         return SWL_ERR_BAD_ARG;
@@ -748,10 +822,104 @@ extern "C" int swl_gemm_skinny_packed_silu_gate_rs(void *out, const void *x, con
     f.ssq_parts = ssq_parts;
     f.eps = eps;
     const dim3 grid((I / 32 + 1) / 2, 1);
+    if (ssq_parts > 8) { // one partial per 16-column tile of the residual row (swl_gemm_rows_add_scale): LDS-DMA + in-kernel sum
+        if (!swl::aligned16(row_ssq) || ((static_cast<int64_t>(ssq_parts) * M) & 3)) return SWL_ERR_BAD_ARG;
+        SWL_DISPATCH_DTYPE(dtype, T, {
+            if (swl::use_ring(K))
+                hipLaunchKernelGGL((swl::gemm_skinny_ring_kernel<T, swl::kGemmSiluGate, true, 3, swl::kGemmWaves, true>), grid,
+                                   dim3(swl::kGemmWaves * 64), 0, static_cast<hipStream_t>(stream), out,
+                                   static_cast<const T *>(x), static_cast<const T *>(w_up_gate_packed), M, I, K, K,
+                                   x_row_stride, out_row_stride, f);
+            else
+                hipLaunchKernelGGL((swl::gemm_skinny_ring_kernel<T, swl::kGemmSiluGate, true, 2, swl::kGemmWaves, true>), grid,
+                                   dim3(swl::kGemmWaves * 64), 0, static_cast<hipStream_t>(stream), out,
+                                   static_cast<const T *>(x), static_cast<const T *>(w_up_gate_packed), M, I, K, K,
+                                   x_row_stride, out_row_stride, f);
+        });
+        return swl::check_launch();
+    }
     SWL_DISPATCH_DTYPE(dtype, T, {
         swl::launch_packed<T, swl::kGemmSiluGate>(grid, static_cast<hipStream_t>(stream), out, static_cast<const T *>(x),
                                                   static_cast<const T *>(w_up_gate_packed), M, I, K, K, x_row_stride,
                                                   out_row_stride, f);
+    });
+    return swl::check_launch();
+}
+
+/* ---- norm on the fly: the projections that consume the RAW residual stream swl_gemm_rows_add leaves behind -------------
+ * x = the residual rows r[M, K] (no consumer launch computed round(r * norm_w) or the sums of squares); the kernel stages
+ * round(r * norm_w) itself (swl_splitk_add_scale's bits) and adds up sum r^2 per row in fp32 while it does.
+ *   swl_gemm_skinny_packed_partial_nf: swl_gemm_skinny_packed_partial (even splits) + ssq_out[k_splits][M], the row_ssq
+ *     swl_paged_attn_decode_qkv_rs takes with ssq_parts = k_splits. The fused qkv projection, transformer_layer.py:46-56.
+ *   swl_gemm_skinny_packed_silu_gate_nf: swl_gemm_skinny_packed_silu_gate_rs with rstd from its own sums.
+ *     transformer_layer.py:120-127. */
+extern "C" int swl_gemm_skinny_packed_partial_nf(float *slabs, size_t slabs_bytes, float *ssq_out, const void *x,
+                                                 const void *norm_w, const void *w_packed, int32_t M, int32_t N, int32_t K,
+                                                 int64_t x_row_stride, int32_t k_splits, int32_t dtype,
+                                                 swl_stream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
+    if (M == 0) return SWL_OK;
+    if (!slabs || !ssq_out || !x || !norm_w || !w_packed || k_splits < 1 || k_splits > 16 || (k_splits & (k_splits - 1)))
+        return SWL_ERR_BAD_ARG;
+    if (M > 32 || (N & 31) || K % (swl::kKT * k_splits)) return SWL_ERR_UNSUPPORTED;
+    if (x_row_stride < K || (x_row_stride & 7) || !swl::aligned16(x) || !swl::aligned16(w_packed) ||
+        !swl::aligned16(norm_w) || !swl::aligned16(slabs))
+        return SWL_ERR_BAD_ARG;
+    if (slabs_bytes < static_cast<size_t>(k_splits) * M * N * sizeof(float)) return SWL_ERR_BAD_ARG;
+    swl::GemmExtra f{};
+    f.norm_w = norm_w;
+    f.ssq_out = ssq_out;
+    const int kc = K / k_splits;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t n64 = N;
+#define SWL_NF_PARTIAL(RD_, NWV_)                                                                                        \
+    hipLaunchKernelGGL((swl::gemm_skinny_ring_kernel<T, swl::kGemmPartial, true, RD_, NWV_, false, true>), grid,          \
+                       dim3(NWV_ * 64), 0, s, static_cast<void *>(slabs), static_cast<const T *>(x),                     \
+                       static_cast<const T *>(w_packed), M, N, K, kc, x_row_stride, n64, f)
+    SWL_DISPATCH_DTYPE(dtype, T, {
+        // (three-wave workgroups stage 3 row groups per wave: with the norm weights and the fp32 staging temporaries a
+        // 3-deep weight ring no longer fits 256 registers — 11-30 spilled; they run the 2-deep ring. A/B on MI355X: the
+        // spilling deep ring and 4-wave workgroups with the deep ring — 192 instead of 256 of them for Llama-3-8B — are
+        // within noise of it in the layer chain: profiles/r05c_rows_layer_micro_nf_rd3 / _nf_4w.jsonl.)
+        if (swl::prefer_three_waves(N, k_splits)) {
+            const dim3 grid(N / 32 / 3, k_splits);
+            SWL_NF_PARTIAL(2, 3);
+        } else {
+            const dim3 grid((N / 32 + swl::kGemmWaves - 1) / swl::kGemmWaves, k_splits);
+            if (swl::use_ring(kc)) SWL_NF_PARTIAL(3, 4);
+            else SWL_NF_PARTIAL(2, 4);
+        }
+    });
+#undef SWL_NF_PARTIAL
+    return swl::check_launch();
+}
+
+extern "C" int swl_gemm_skinny_packed_silu_gate_nf(void *out, const void *x, const void *norm_w, float eps,
+                                                   const void *w_up_gate_packed, int32_t M, int32_t I, int32_t K,
+                                                   int64_t x_row_stride, int64_t out_row_stride, int32_t dtype,
+                                                   swl_stream_t stream) {
+    if (M < 0 || I <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
+    if (M == 0) return SWL_OK;
+    if (!out || !x || !norm_w || !w_up_gate_packed) return SWL_ERR_BAD_ARG;
+    if (M > 32 || (I & 31) || (K & (swl::kKT - 1))) return SWL_ERR_UNSUPPORTED;
+    if (x_row_stride < K || out_row_stride < I || (x_row_stride & 7) || (out_row_stride & 3)) return SWL_ERR_BAD_ARG;
+    if (!swl::aligned16(x) || !swl::aligned16(w_up_gate_packed) || !swl::aligned16(norm_w) ||
+        (reinterpret_cast<uintptr_t>(out) & 7u))
+        return SWL_ERR_BAD_ARG;
+    swl::GemmExtra f{};
+    f.norm_w = norm_w;
+    f.eps = eps;
+    const dim3 grid((I / 32 + 1) / 2, 1);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    SWL_DISPATCH_DTYPE(dtype, T, {
+        if (swl::use_ring(K))
+            hipLaunchKernelGGL((swl::gemm_skinny_ring_kernel<T, swl::kGemmSiluGate, true, 3, swl::kGemmWaves, false, true>),
+                               grid, dim3(swl::kGemmWaves * 64), 0, s, out, static_cast<const T *>(x),
+                               static_cast<const T *>(w_up_gate_packed), M, I, K, K, x_row_stride, out_row_stride, f);
+        else
+            hipLaunchKernelGGL((swl::gemm_skinny_ring_kernel<T, swl::kGemmSiluGate, true, 2, swl::kGemmWaves, false, true>),
+                               grid, dim3(swl::kGemmWaves * 64), 0, s, out, static_cast<const T *>(x),
+                               static_cast<const T *>(w_up_gate_packed), M, I, K, K, x_row_stride, out_row_stride, f);
     });
     return swl::check_launch();
 }

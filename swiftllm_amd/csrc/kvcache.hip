@@ -56,6 +56,7 @@ __global__ __launch_bounds__(128) void store_kv_decode_kernel(
     const int64_t i = blockIdx.x;
     const int seq_id = seq_ids[i];
     const int pos = seq_lens[i] - 1;
+    if (pos < 0) return; // an inert row of a padded decode batch (length 0)
     const int64_t blk = block_table[static_cast<int64_t>(seq_id) * max_blocks_per_seq + pos / block_size];
     const int slot = pos % block_size;
     const int64_t base = (blk * num_layers + cur_layer) * KVH * static_cast<int64_t>(block_size) * D +

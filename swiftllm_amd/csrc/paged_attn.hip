@@ -671,6 +671,7 @@ __global__ __launch_bounds__(64) void paged_attn_phase2_kernel(
     const int seq = blockIdx.y;
     const int lane = threadIdx.x;
     const int len = seq_lens[seq];
+    if (len <= 0) return; // an inert row of a padded decode batch: phase 1 wrote no partials for it
     const int n = (len + seq_block_size - 1) / seq_block_size;
     const int64_t base = (static_cast<int64_t>(seq) * H + head) * num_seq_blocks;
     constexpr int VD = (D + 63) / 64;

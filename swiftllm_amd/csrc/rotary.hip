@@ -29,6 +29,7 @@ __global__ __launch_bounds__(256) void rotary_kernel(T *__restrict__ q, T *__res
         const int hh = static_cast<int>(th % heads);
         const int64_t tok = th / heads;
         const int64_t row = pos_idx ? pos_idx[tok] : tok;
+        if (row < 0) continue; // an inert row of a padded decode batch (length 0: worker/model.py, hipGraph buckets)
         const vec8_t<T> cv = load8(cos_t + row * (D >> 1) + c * 8);
         const vec8_t<T> sv = load8(sin_t + row * (D >> 1) + c * 8);
         T *base = hh < H ? q + tok * q_tok_stride + static_cast<int64_t>(hh) * D
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(256) void rotary_store_decode_kernel(
     const int64_t qkv_row = static_cast<int64_t>(H + 2 * KVH) * D;
     const int seq_id = seq_ids[tok];
     const int pos = seq_lens[tok] - 1;
+    if (pos < 0) return; // an inert row of a padded decode batch (length 0): nothing rotated, nothing stored
     const int64_t row = pos_idx ? pos_idx[tok] : pos;
     const int64_t blk = block_table[static_cast<int64_t>(seq_id) * max_blocks_per_seq + pos / block_size];
     const int slot = pos % block_size;

@@ -66,6 +66,11 @@ class EngineConfig:
         # batches of <= 2 sequences: the qkv and up/gate projections sum the previous projection's slabs themselves
         # (csrc/gemm_tiny.hip), 5 launches per layer instead of 7
         tiny_decode_batches=True,
+        # decode batches of <= 32 sequences, bfloat16: o_proj — and down_proj up to 8 sequences — finish their rows INSIDE the
+        # workgroup that owns them (csrc/gemm_rows.hip: K split across the 8 waves, residual add in the epilogue: no slabs,
+        # no consumer launch), and the projection that follows applies the norm weight and the 1/rms itself while it stages
+        # the raw residual rows ("norm on the fly", gemm_skinny.hip NF): 6 launches per layer at batch 32, 5 up to batch 8
+        rows_decode=True,
         pin_swap_memory=True,           # host swap pool in pinned memory (falls back to pageable when the host refuses)
     )
 

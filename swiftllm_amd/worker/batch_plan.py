@@ -61,6 +61,13 @@ class BatchPlan:
     decoding_seq_lens: np.ndarray       # [Bd]
     position_indices: np.ndarray        # [T]
     last_token_indices: np.ndarray      # [B]
+    # sequences of the caller's batch; batch_size - num_real_seqs trailing rows are inert padding (length 0) that rounds a
+    # pure-decode batch up to its hipGraph bucket (worker/model.py: _decode_batch_bucket). -1: not set = batch_size
+    num_real_seqs: int = -1
+
+    @property
+    def real_seqs(self) -> int:
+        return self.num_real_seqs if self.num_real_seqs >= 0 else self.batch_size
 
     SEGMENTS = ("input_ids", "seq_ids", "seq_lengths", "prefill_seq_lens",
                 "prefill_start_locs_with_end", "decoding_seq_lens", "position_indices",

@@ -313,6 +313,103 @@ def linear_silu_gate(a: torch.Tensor, w_up_gate: torch.Tensor, row_scale=None):
     return out
 
 
+# ---- o_proj with K split inside the workgroup + residual add + deferred-norm half in its epilogue (csrc/gemm_rows.hip) --
+_ROWS_MAX_PARTS = 256       # kSsqManyParts: sums-of-squares partials the SiLU-gate GEMM adds itself (one per 16 columns)
+
+
+def rows_add_scale_ok(a: torch.Tensor, w: torch.Tensor, residual: torch.Tensor) -> bool:
+    """Can `linear_rows_add_scale` run o_proj + residual add + round(residual * norm_w) in one launch? bfloat16 (the
+    deferred norm's policy, kernels/rmsnorm.py: deferred_norm_ok), <= 32 tokens, packed weight, hidden <= 4096."""
+    if _packed_of(w) is None or not _skinny_ok(a, w) or a.dtype != torch.bfloat16:
+        return False
+    m, k = a.shape
+    n = w.shape[0]
+    return (residual.is_contiguous() and residual.shape == (m, n) and n // 16 <= _ROWS_MAX_PARTS
+            and bool(_hip.load().swl_gemm_rows_supported(m, n, k)))
+
+
+def linear_rows_add_scale(a: torch.Tensor, w: torch.Tensor, residual_io: torch.Tensor, norm_w: torch.Tensor, eps: float):
+    """residual_io += round(a @ w^T); returns RowScalePending(round(residual_io * norm_w), ssq[N/16, M]) — what
+    linear_splitk + add_scale_from_splitk return, in one launch and without slabs (another fp32 summation order of the
+    same products: K/8 runs per wave added in K order)."""
+    from .rmsnorm import RowScalePending
+    assert rows_add_scale_ok(a, w, residual_io) and norm_w.dtype == a.dtype and norm_w.is_contiguous()
+    m, k = a.shape
+    n = w.shape[0]
+    xs = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    parts = n // 16
+    ssq = torch.empty((parts, m), dtype=torch.float32, device=a.device)
+    _hip.call("swl_gemm_rows_add_scale", _hip.ptr(xs), _hip.ptr(residual_io), _hip.ptr(ssq), _hip.ptr(norm_w), _hip.ptr(a),
+              _hip.ptr(_packed_of(w)), m, n, k, _row_stride(a), _hip.dtype_code(a.dtype), _hip.stream())
+    return RowScalePending(xs, ssq, parts, eps)
+
+
+class RawResidual:
+    """What a layer hands to the next one when its down projection already added itself into the residual buffer
+    (linear_rows_add): there is no activation tensor and no slabs — the residual rows ARE the layer output, and the next
+    projection normalises them on the fly (linear_splitk_nf)."""
+    __slots__ = ("shape", "dtype")
+
+    def __init__(self, residual: torch.Tensor):
+        self.shape, self.dtype = tuple(residual.shape), residual.dtype
+
+
+def rows_add_ok(a: torch.Tensor, w: torch.Tensor, residual: torch.Tensor) -> bool:
+    """Can `linear_rows_add` run the projection + residual add in one launch (no slabs)? Packed weight, <= 32 tokens."""
+    if _packed_of(w) is None or not _skinny_ok(a, w):
+        return False
+    m, k = a.shape
+    n = w.shape[0]
+    return (residual.is_contiguous() and residual.shape == (m, n) and residual.dtype == a.dtype
+            and bool(_hip.load().swl_gemm_rows_supported(m, n, k)))
+
+
+def linear_rows_add(a: torch.Tensor, w: torch.Tensor, residual_io: torch.Tensor) -> torch.Tensor:
+    """residual_io += round(a @ w^T), in place, one launch: the workgroup that owns 16 rows of w for all of K finishes
+    them itself (csrc/gemm_rows.hip). Returns residual_io."""
+    assert rows_add_ok(a, w, residual_io)
+    m, k = a.shape
+    _hip.call("swl_gemm_rows_add", _hip.ptr(residual_io), _hip.ptr(a), _hip.ptr(_packed_of(w)), m, w.shape[0], k,
+              _row_stride(a), _hip.dtype_code(a.dtype), _hip.stream())
+    return residual_io
+
+
+def nf_ok(r: torch.Tensor, w: torch.Tensor, norm_w: torch.Tensor) -> bool:
+    """Can a projection stage round(r * norm_w) itself (norm on the fly)? Packed weight, <= 32 tokens, bfloat16 (the
+    deferred norm's policy: kernels/rmsnorm.py deferred_norm_ok)."""
+    return (_packed_of(w) is not None and _skinny_ok(r, w) and r.dtype == torch.bfloat16 and norm_w.dtype == r.dtype
+            and norm_w.is_contiguous() and norm_w.numel() == r.shape[1])
+
+
+def linear_splitk_nf(r: torch.Tensor, norm_w: torch.Tensor, w: torch.Tensor, eps: float):
+    """linear_splitk(round(r * norm_w), w, always=True) with the rows' sums of squares on the side: returns (SplitKPartials,
+    RowScalePending) — the pending 1/rms is applied by the consumer of the slabs (paged_attention_from_qkv_splitk)."""
+    from .rmsnorm import RowScalePending
+    assert nf_ok(r, w, norm_w)
+    m, k = r.shape
+    n = w.shape[0]
+    ks = int(_hip.load().swl_gemm_skinny_packed_choose_splits(n, k))
+    if k % (128 * ks):
+        return None
+    ws = _workspace(r.device, ks * m * n * 4)
+    ssq = torch.empty((ks, m), dtype=torch.float32, device=r.device)
+    _hip.call("swl_gemm_skinny_packed_partial_nf", _hip.ptr(ws), ws.numel() * 4, _hip.ptr(ssq), _hip.ptr(r), _hip.ptr(norm_w),
+              _hip.ptr(_packed_of(w)), m, n, k, _row_stride(r), ks, _hip.dtype_code(r.dtype), _hip.stream())
+    return SplitKPartials(ws, ks, m, n, r.dtype), RowScalePending(None, ssq, ks, eps, k)
+
+
+def linear_silu_gate_nf(r: torch.Tensor, norm_w: torch.Tensor, eps: float, w_up_gate: torch.Tensor) -> torch.Tensor:
+    """silu_and_mul(rmsnorm(r) * norm_w @ up_gate^T)[:, :I] from the raw residual rows, one launch: the norm weight is applied
+    while the rows are staged, the 1/rms (from the kernel's own sums of squares) in fp32 before the projection's rounding."""
+    assert nf_ok(r, w_up_gate, norm_w) and w_up_gate.shape[0] % 64 == 0
+    m, k = r.shape
+    inter = w_up_gate.shape[0] // 2
+    out = torch.empty((m, inter), dtype=r.dtype, device=r.device)
+    _hip.call("swl_gemm_skinny_packed_silu_gate_nf", _hip.ptr(out), _hip.ptr(r), _hip.ptr(norm_w), eps,
+              _hip.ptr(_packed_of(w_up_gate)), m, inter, k, _row_stride(r), inter, _hip.dtype_code(r.dtype), _hip.stream())
+    return out
+
+
 # ---- very small decode batches: the projection sums the previous projection's slabs itself (csrc/gemm_tiny.hip) ------
 _TINY_MAX_M = 4             # swl_gemm_tiny_max_tokens(): what the kernels accept
 _TINY_POLICY_M = 2          # what the layer uses them for: each workgroup re-reads 8 slabs x M x K-chunk through its L1

@@ -23,6 +23,12 @@ take up to 4; bfloat16 only, as it rides on the deferred norm): the two consumer
 qkv projection and the up/gate projection sum the previous projection's slabs themselves while their first weight
 tiles are in flight (kernels/linear.py: linear_splitk_from_splitk / linear_silu_gate_from_splitk, csrc/gemm_tiny.hip),
 the residual stream ping-pongs between two buffers: 5 launches per layer instead of 7.
+
+Row-owned projections (rows_decode, bfloat16, on the deferred-norm path): o_proj for <= ROWS_O_MAX_M sequences and down_proj for
+<= ROWS_DOWN_MAX_M add themselves into the residual buffer in their own epilogue (kernels/linear.py: linear_rows_add,
+csrc/gemm_rows.hip) and the next projection normalises the raw residual rows while it stages them (linear_silu_gate_nf /
+linear_splitk_nf): no slabs and no consumer launch on that side. A layer whose down projection ran that way returns a
+RawResidual marker instead of an activation tensor.
 """
 import torch
 
@@ -31,6 +37,7 @@ from ..kernels.linear import _TINY_POLICY_M as TINY_POLICY_M
 from ..kernels.linear import attn_partials_ok, linear_splitk_from_attn_partials
 from ..kernels.linear import (row_scaled_silu_gate_ok, alt_residual_like, linear_silu_gate_from_splitk,
                               linear_splitk_from_splitk, tiny_from_splitk_ok)
+from ..kernels.linear import RawResidual, linear_rows_add, linear_silu_gate_nf, linear_splitk_nf, nf_ok, rows_add_ok
 from ..kernels.rmsnorm import RowScalePending
 from ..kernels.rmsnorm import (add_scale_from_splitk, deferred_norm_ok, fused_add_rmsnorm_inplace,
                                fused_add_rmsnorm_from_splitk)
@@ -43,6 +50,12 @@ from ..kernels.silu_and_mul import silu_and_mul_inplace
 
 
 class LlamaTransformerLayer:
+    # Where the row-owned projections win on MI355X (tools/gemm_rows_micro.py --layer, profiles/r05c_*): every workgroup
+    # of such a projection pulls ALL of x through its own L1 at ~55 GB/s, so the win shrinks with the batch — o_proj (x =
+    # M x 8 KiB) ties the split-K pair at 32 sequences, down_proj (x = M x 28 KiB) at 16.
+    ROWS_O_MAX_M = 32
+    ROWS_DOWN_MAX_M = 8
+
     def __init__(self, model_config, engine_config, weight, decoding_piggyback_stream, layer_id: int):
         self.model_config = model_config
         self.engine_config = engine_config
@@ -50,6 +63,7 @@ class LlamaTransformerLayer:
         self.decoding_piggyback_stream = decoding_piggyback_stream
         self.layer_id = layer_id
         self.skinny = bool(getattr(engine_config, "use_skinny_gemm", False))
+        self._cur_state = None      # the infer state of the forward in progress (the post-attention half reads it)
         self._qkv_splits = None     # k-splits the skinny GEMM picks for the fused qkv projection (cached)
         self._tiny_ok = None        # can this layer run the tiny-batch (<= TINY_POLICY_M sequences) path (cached)
 
@@ -73,9 +87,12 @@ class LlamaTransformerLayer:
     def forward(self, input_embds, residual_buf: torch.Tensor, k_cache: torch.Tensor,
                 v_cache: torch.Tensor, block_table: torch.Tensor, infer_state):
         cfg, ecfg, w, st = self.model_config, self.engine_config, self.weight, infer_state
+        self._cur_state = st
 
         # residual_buf <- input_embds + residual_buf ; input_embds <- rmsnorm(residual_buf)
         row_scale = None
+        if isinstance(input_embds, RawResidual):        # the previous layer's down projection is already in residual_buf
+            return self._forward_from_raw_residual(residual_buf, k_cache, v_cache, block_table, st)
         if isinstance(input_embds, SplitKPartials):     # the previous layer's down projection, unreduced
             if self._tiny_decode_applies(st, input_embds, residual_buf):
                 return self._forward_decode_tiny(input_embds, residual_buf, k_cache, v_cache, block_table, st)
@@ -110,6 +127,28 @@ class LlamaTransformerLayer:
                       else lib.swl_gemm_skinny_choose_splits)     # what linear_splitk will pick for this weight
             self._qkv_splits = int(choose(w.qkv_proj.shape[0], w.qkv_proj.shape[1]))
         return self._qkv_splits in (1, 2, 4)
+
+    def _rows_applies(self, st, residual_buf, w_proj, x, max_m: int) -> bool:
+        """Row-owned projection + norm on the fly for this batch: rows_decode, the deferred-norm conditions (bfloat16,
+        slab-fed attention), <= max_m sequences, a packed weight the rows kernel takes."""
+        ecfg = self.engine_config
+        return (getattr(ecfg, "rows_decode", False) and st.num_decoding_seqs <= max_m and self._deferred_attn_norm_ok(st)
+                and rows_add_ok(x, w_proj, residual_buf))
+
+    def _forward_from_raw_residual(self, residual_buf, k_cache, v_cache, block_table, st):
+        """residual_buf holds the layer input r (the previous down projection added itself): qkv slabs of
+        round(r * attn_norm) with the 1/rms pending -> slab-fed attention -> the rest of the layer."""
+        cfg, ecfg, w = self.model_config, self.engine_config, self.weight
+        qkv, pend = linear_splitk_nf(residual_buf, w.attn_norm, w.qkv_proj, cfg.rms_norm_eps)
+        o = torch.empty_like(residual_buf)
+        paged_attention_from_qkv_splitk(qkv, k_cache, v_cache, block_table, cfg, ecfg, st, self.layer_id, o,
+                                        row_scale=pend)
+        return self._forward_after_attention(o, residual_buf, True)
+
+    def _qkv_splits_even(self) -> bool:
+        """linear_splitk_nf takes even K splits only (set by _deferred_attn_norm_ok, which every caller checked first)."""
+        w = self.weight
+        return self._qkv_splits is not None and w.qkv_proj.shape[1] % (128 * self._qkv_splits) == 0
 
     def _tiny_decode_applies(self, st, partials, residual_buf) -> bool:
         """<= TINY_POLICY_M (2) decoding sequences on the deferred-norm fast path, every projection of the layer split over K (so the
@@ -219,6 +258,17 @@ class LlamaTransformerLayer:
 
     def _forward_after_attention(self, input_embds, residual_buf, fast: bool):
         cfg, w = self.model_config, self.weight
+        st = self._cur_state
+        if (fast and st is not None and self._rows_applies(st, residual_buf, w.o_proj, input_embds, self.ROWS_O_MAX_M)
+                and nf_ok(residual_buf, w.up_gate_proj, w.ffn_norm) and w.up_gate_proj.shape[0] % 64 == 0):
+            # o_proj adds itself into the residual; the SiLU-gate GEMM normalises the raw rows on the fly
+            linear_rows_add(input_embds, w.o_proj, residual_buf)
+            act = linear_silu_gate_nf(residual_buf, w.ffn_norm, cfg.rms_norm_eps, w.up_gate_proj)
+            if (self._rows_applies(st, residual_buf, w.down_proj, act, self.ROWS_DOWN_MAX_M)
+                    and nf_ok(residual_buf, w.qkv_proj, w.attn_norm) and self._qkv_splits_even()):
+                linear_rows_add(act, w.down_proj, residual_buf)
+                return RawResidual(residual_buf)
+            return linear_splitk(act, w.down_proj)
         if fast:
             attn_out = linear_splitk(input_embds, w.o_proj)
             if isinstance(attn_out, SplitKPartials):

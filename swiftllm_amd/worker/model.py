@@ -35,7 +35,8 @@ from .batch_plan import BatchPlan, plan_batch
 from .block_manager import BlockManager
 from .infer_state import LlamaInferState
 from .kernels.block_swapping import swap_blocks
-from .kernels.rmsnorm import fused_add_rmsnorm_from_splitk
+from .kernels.linear import RawResidual
+from .kernels.rmsnorm import fused_add_rmsnorm_from_splitk, rmsnorm_inplace
 from .layers.pre_layer import LlamaPreLayer
 from .layers.transformer_layer import LlamaTransformerLayer
 from .layers.post_layer import LlamaPostLayer
@@ -102,6 +103,7 @@ class LlamaModel:
         self._host_prof = {} if os.environ.get("SWL_HOST_PROFILE") else None
         self._graph_pool = None
         self._scratch = None
+        self.graph_captures = 0      # hipGraph captures so far (each = one warm-up forward + one capture): serving reports it
 
     # ------------------------------------------------------------------------------------------------
     @torch.inference_mode()
@@ -285,6 +287,10 @@ class LlamaModel:
         block_table = None if infer_state.ignore_kvcache else self.gpu_block_manager.block_table
         for layer in self.transformer_layers:
             x = layer.forward(x, residual, self.k_cache, self.v_cache, block_table, infer_state)
+        if isinstance(x, RawResidual):          # the last down projection added itself into the residual (rows_decode):
+            x = residual.clone()                # pure decode, every row a last token — final norm of the residual rows
+            rmsnorm_inplace(x, self.weight.final_norm, self.model_config.rms_norm_eps)
+            return self.post_layer.forward_normed(x)
         if not isinstance(x, torch.Tensor):     # the last down projection left as split-K partials
             if infer_state.num_prefill_seqs == 0:
                 # pure decode: every row is a last token — reduce + residual add + final norm in one launch
@@ -295,7 +301,7 @@ class LlamaModel:
         return self.post_layer.forward(x, infer_state)
 
     # ---- hipGraph replay of pure-decode steps ------------------------------------------------------------
-    _MAX_DECODE_GRAPHS = 24     # LRU bound of the replay cache (each graph pins its activations + [B, vocab] logits)
+    _MAX_DECODE_GRAPHS = 48     # LRU bound of the replay cache (each graph pins its activations + [B, vocab] logits)
 
     def _graph_bucket(self, plan: BatchPlan):
         """Captured launch geometry must cover every replay, and the number of distinct geometries a long-running
@@ -320,6 +326,33 @@ class LlamaModel:
             sbs = max(256, 1 << (horizon - 1).bit_length())
         return sbs, nsb_cap
 
+    def _decode_batch_bucket(self, batch: int) -> int:
+        """Captured batch size that serves a pure-decode batch of `batch` sequences. The replay cache is keyed on the batch
+        size, and a server's batch drifts by one sequence at a time: keyed on the EXACT size (r01-r04) every new size paid a
+        warm-up forward plus a capture. Sizes are rounded up — to a multiple of 8 up to 64 sequences, of 16 beyond (the
+        projections' cost moves in 32-token blocks there) — and the surplus rows are INERT: length-0 sequences, which every
+        decode kernel treats as a no-op (paged attention: the workgroup exits before its prologue; rotary / KV store: nothing
+        read, nothing stored; the projections, norms and the sampler are row-independent, so whatever an inert row holds
+        never reaches a real one). 1 and 2 stay exact (their own launch path). The reference has no graphs
+        (swiftllm/worker/model.py:228-249 launches eagerly); results are those of the exact-size launch."""
+        if batch <= 2:
+            return batch
+        step = 8 if batch <= 64 else 16
+        return -(-batch // step) * step
+
+    def _plan_decode(self, seq_ids_list: List[int], lens: List[int], tokens, pad: bool) -> BatchPlan:
+        """Plan of a pure-decode step; `pad`: rounded up to its batch bucket with inert rows (token 0, length 0)."""
+        b = len(lens)
+        bp = self._decode_batch_bucket(b) if pad else b
+        ids = tokens if tokens is not None else [(0,)] * b
+        if bp > b:
+            ids = list(ids) + [(0,)] * (bp - b)
+            seq_ids_list = list(seq_ids_list) + [seq_ids_list[0]] * (bp - b)
+            lens = list(lens) + [0] * (bp - b)
+        plan = plan_batch(ids, seq_ids_list, lens, self.model_config.num_kv_heads, self._num_slots)
+        plan.num_real_seqs = b
+        return plan
+
     def _forward_decode_graph(self, plan: BatchPlan, dev: dict) -> torch.Tensor:
         sbs, nsb_cap = self._graph_bucket(plan)
         key = (plan.batch_size, sbs, nsb_cap)
@@ -328,6 +361,7 @@ class LlamaModel:
         tap = self.post_layer.logits_tap
         tap_len = len(tap) if tap is not None else 0
         if entry is None:
+            self.graph_captures += 1
             state = self._make_infer_state(plan, dev, False)
             # one eager run on a side stream first (library handles, workspaces, allocator pools):
             # nothing may be lazily initialised while the stream is capturing
@@ -352,9 +386,10 @@ class LlamaModel:
                 del tap[tap_len:]               # what the warm-up run and the capture appended
         self._decode_graphs[key] = entry        # (re)inserted last = most recently used
         entry.graph.replay()
+        n = plan.real_seqs
         if tap is not None:                     # (tests) one entry per forward, as on the eager path; a copy: the
-            tap.append(entry.logits.clone())    # graph's own tensor is overwritten by the next replay
-        return entry.out_tokens
+            tap.append(entry.logits[:n].clone())    # graph's own tensor is overwritten by the next replay
+        return entry.out_tokens[:n]
 
     # ---- decode look-ahead: the host side of step k+1 runs while the GPU executes step k ---------------------------------
     def _prepare_next_decode(self, plan: BatchPlan, seq_ids_list: List[int], tokens_dev: torch.Tensor):
@@ -366,11 +401,11 @@ class LlamaModel:
         (tools/host_overhead.py: plan 18 + upload 24 us at batch 32). If it is not, nothing is lost: the ordinary path
         re-plans and re-uploads. (Blocks are NOT taken early: a scheduler that counts the pool down to its last block must
         find the allocator exactly where its own books say it is.)"""
-        next_lens = [n + 1 for n in plan.seq_lengths_list]
+        b = plan.real_seqs
+        next_lens = [n + 1 for n in plan.seq_lengths_list[:b]]
         if max(next_lens) > self._cos_cached.shape[0]:
             return None
-        nxt = plan_batch([(0,)] * plan.batch_size, seq_ids_list, next_lens, self.model_config.num_kv_heads,
-                         self._num_slots)
+        nxt = self._plan_decode(seq_ids_list, next_lens, None, True)
         layout, total = nxt.packed_layout()
         if self._la_host is None or self._la_host.numel() < total:
             self._la_host = torch.empty(max(total, self._meta_host.numel()), dtype=torch.int32, pin_memory=True)
@@ -382,7 +417,7 @@ class LlamaModel:
         self._meta_dev[:total].copy_(self._la_host[:total], non_blocking=True)
         self._la_done.record()
         dev = {name: self._meta_dev[off:off + n] for name, off, n in layout}
-        dev["input_ids"].copy_(tokens_dev)      # int64 -> int32 on the device: the host has not seen them yet
+        dev["input_ids"][:b].copy_(tokens_dev)  # int64 -> int32 on the device: the host has not seen them yet (inert rows: 0)
         la = _DecodeLookahead()
         la.seq_ids, la.lens, la.plan, la.dev, la.tokens = list(seq_ids_list), next_lens, nxt, dev, None
         return la
@@ -414,7 +449,7 @@ class LlamaModel:
         t0 = time.perf_counter() if prof is not None else 0.0
         la = self._take_lookahead(input_ids_list, seq_ids_list, decoding_seq_lens_list, ignore_kvcache)
         if la is not None:      # the step that was prepared while the previous one ran: blocks, then the launch
-            self.gpu_block_manager.allocate_blocks_for_seqs(la.seq_ids, la.lens)
+            self.gpu_block_manager.allocate_blocks_for_seqs(la.seq_ids, la.lens)   # (the real sequences only)
             tokens = self._forward_decode_graph(la.plan, la.dev)
             nxt = self._prepare_next_decode(la.plan, la.seq_ids, tokens)
             if self.after_launch_hook is not None:
@@ -429,8 +464,16 @@ class LlamaModel:
                                  ("lookahead_hits", 1.0)):
                     prof[name] = prof.get(name, 0.0) + dt
             return out
-        plan = plan_batch(input_ids_list, seq_ids_list, decoding_seq_lens_list,
-                          self.model_config.num_kv_heads, self._num_slots)
+        num_real = len(input_ids_list)
+        graph_step = (len(decoding_seq_lens_list) == num_real and not ignore_kvcache
+                      and getattr(self.engine_config, "use_hip_graph", False))
+        if graph_step or (self._eager_uses_graph_buckets and len(decoding_seq_lens_list) == num_real and not ignore_kvcache):
+            # pure decode on the replay path: the batch is rounded up to its bucket with inert rows (_decode_batch_bucket)
+            plan = self._plan_decode(seq_ids_list, list(decoding_seq_lens_list), input_ids_list, True)
+        else:
+            plan = plan_batch(input_ids_list, seq_ids_list, decoding_seq_lens_list,
+                              self.model_config.num_kv_heads, self._num_slots)
+            plan.num_real_seqs = num_real
         longest = max(plan.seq_lengths_list)
         if longest > self._cos_cached.shape[0]:
             # the reference indexes its rope cache out of range here (model.py:350); fail on the host
@@ -439,7 +482,7 @@ class LlamaModel:
                 "max_position_embeddings * rope_scaling + 128); use a checkpoint with rope scaling")
         t1 = time.perf_counter() if prof is not None else 0.0
         if not ignore_kvcache:
-            self.gpu_block_manager.allocate_blocks_for_seqs(seq_ids_list, plan.seq_lengths_list)
+            self.gpu_block_manager.allocate_blocks_for_seqs(seq_ids_list, plan.seq_lengths_list[:num_real])
         t2 = time.perf_counter() if prof is not None else 0.0
         dev = self._upload_plan(plan)
         t3 = time.perf_counter() if prof is not None else 0.0
@@ -452,7 +495,10 @@ class LlamaModel:
         else:
             if pure_decode and not ignore_kvcache and self._eager_uses_graph_buckets:
                 plan.seq_block_size, plan.num_seq_blocks = self._graph_bucket(plan)
-            tokens = self._forward(dev["input_ids"], self._make_infer_state(plan, dev, ignore_kvcache))
+            tokens = self._forward(dev["input_ids"], self._make_infer_state(plan, dev, ignore_kvcache))[:num_real]
+            tap = self.post_layer.logits_tap
+            if tap and plan.batch_size > num_real:      # (tests) a padded eager step: the real rows only, as on replay
+                tap[-1] = tap[-1][:num_real]
         if self.after_launch_hook is not None:
             self.after_launch_hook()
         if prof is None:

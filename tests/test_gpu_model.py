@@ -373,9 +373,10 @@ def test_tiny_batch_decode_path_equals_the_consumer_path(tmp_path, dtype, batch)
         torch.cuda.empty_cache()
         return toks, logits
 
-    ref_toks, ref_logits = run(dict(tuning=dict(tiny_decode_batches=False)))
+    # (rows_decode off on both sides: with it on, bfloat16 batches of <= 8 never reach the tiny path — tests/test_gpu_rows.py)
+    ref_toks, ref_logits = run(dict(tuning=dict(tiny_decode_batches=False, rows_decode=False)))
     eps = 2.0 ** -10 if dtype == "float16" else 2.0 ** -7
-    for opts in (dict(), dict(use_hip_graph=False)):
+    for opts in (dict(tuning=dict(rows_decode=False)), dict(use_hip_graph=False, tuning=dict(rows_decode=False))):
         toks, logits = run(opts, forced=ref_toks)
         for step, (a, b) in enumerate(zip(logits, ref_logits)):
             scale = b.abs().amax(dim=1, keepdim=True).clamp(min=1.0)
@@ -632,3 +633,47 @@ def test_large_decode_batches_replay_their_hip_graph_bit_for_bit(tmp_path, batch
     assert runs[True][0] == runs[False][0]
     for a, b in zip(runs[True][1], runs[False][1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_decode_batch_buckets_replay_equals_exact_eager_launches(tmp_path, dtype):
+    """hipGraph replay rounds a pure-decode batch up to its bucket with inert rows (worker/model.py: _decode_batch_bucket):
+    a batch that shrinks 7 -> 6 -> 5 -> 4 -> 3 as sequences finish replays ONE captured graph (batch 8) and returns, step
+    for step, the tokens AND the logits of exact-size eager launches, bit for bit (every decode kernel is row-independent
+    and treats a length-0 sequence as a no-op); the finished sequences' blocks are freed and the KV of the survivors is
+    untouched by the inert rows (they store nothing)."""
+    cfg = synth.make_config(num_hidden_layers=2, hidden_size=1024, num_attention_heads=8, num_key_value_heads=2,
+                            intermediate_size=2048, vocab_size=512, max_position_embeddings=512)
+    tdtype = torch.float16 if dtype == "float16" else torch.bfloat16
+    sd = synth.make_state_dict(cfg, seed=21, dtype=tdtype)
+    g = torch.Generator().manual_seed(8)
+    lens0 = [40, 3, 17, 64, 5, 33, 9]
+    prompts = [torch.randint(0, cfg["vocab_size"], (n,), generator=g).tolist() for n in lens0]
+    runs = {}
+    for graph in (False, True):
+        model = _make_model(tmp_path / f"g{int(graph)}", cfg, sd, 96, max_blocks_per_seq=16, max_tokens_in_batch=512,
+                            max_batch_size=8, max_seqs_in_block_table=16, dtype=dtype, use_hip_graph=graph)
+        seq_ids = list(range(len(prompts)))
+        toks = model.forward(prompts, seq_ids, [])
+        lens = list(lens0)
+        out = [list(toks)]
+        for step in range(10):
+            if step in (2, 4, 6, 8):            # the last sequence finishes
+                model.free_seqs_resources([seq_ids[-1]])
+                seq_ids, lens, toks = seq_ids[:-1], lens[:-1], toks[:-1]
+            lens = [n + 1 for n in lens]
+            toks = model.forward([[t] for t in toks], seq_ids, list(lens))
+            assert len(toks) == len(seq_ids)
+            out.append(list(toks))
+        logits = [t.clone() for t in model.post_layer.logits_tap]
+        runs[graph] = (out, logits)
+        if graph:
+            # one BATCH bucket (8) for the five batch sizes; the split geometry of these short, shrinking sequences adds its
+            # own key dimension (_graph_bucket)
+            assert {k[0] for k in model._decode_graphs} == {8} and model.graph_captures <= 2, list(model._decode_graphs)
+        del model
+        torch.cuda.empty_cache()
+    assert runs[True][0] == runs[False][0]
+    assert len(runs[True][1]) == len(runs[False][1])
+    for a, b in zip(runs[True][1], runs[False][1]):
+        assert a.shape == b.shape and torch.equal(a, b)

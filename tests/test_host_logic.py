@@ -374,6 +374,39 @@ def test_graph_bucket_keeps_splits_balanced_and_few():
     assert len(widths) <= 5 * 4, len(widths)
 
 
+def test_decode_batch_buckets_and_inert_rows():
+    """hipGraph replay keys on the batch rounded up to a bucket (worker/model.py: _decode_batch_bucket) and fills the
+    surplus rows with inert sequences: few distinct buckets over 1..256, never smaller than the batch, at most 15 rows of
+    padding, thresholds of the launch paths (2 / 32 / 64 / 256) are bucket boundaries; the padded plan has the layout
+    of an exact plan of the bucket size (a captured graph finds its metadata at fixed addresses), length 0 / position -1
+    / token 0 in the inert rows, and the planner's split width does not see them."""
+    import types
+    from swiftllm_amd.worker.model import LlamaModel
+    from swiftllm_amd.worker.batch_plan import plan_batch
+    m = LlamaModel.__new__(LlamaModel)
+    m.model_config = types.SimpleNamespace(num_kv_heads=8)
+    m._num_slots = 256
+    buckets = {b: m._decode_batch_bucket(b) for b in range(1, 257)}
+    assert all(v >= b and v - b <= 15 for b, v in buckets.items())
+    assert buckets[1] == 1 and buckets[2] == 2 and buckets[3] == 8 and buckets[32] == 32 and buckets[33] == 40
+    assert buckets[64] == 64 and buckets[65] == 80 and buckets[250] == 256 and buckets[256] == 256
+    assert len(set(buckets.values())) <= 24
+    for limit in (32, 64, 128, 256):     # a batch on one side of a launch-path threshold is never padded across it
+        assert all(v <= limit for b, v in buckets.items() if b <= limit)
+    lens = [1100, 37, 5]
+    plan = m._plan_decode([7, 3, 9], lens, [[11], [12], [13]], True)
+    exact = plan_batch([[0]] * 8, [0] * 8, [1] * 8, 8, 256)
+    assert plan.batch_size == 8 and plan.real_seqs == 3 and plan.packed_layout() == exact.packed_layout()
+    assert plan.input_ids.tolist() == [11, 12, 13, 0, 0, 0, 0, 0]
+    assert plan.decoding_seq_lens.tolist() == lens + [0] * 5 and plan.position_indices.tolist() == [1099, 36, 4] + [-1] * 5
+    assert plan.seq_ids.tolist()[:3] == [7, 3, 9] and plan.seq_lengths_list[:3] == lens
+    unpadded = m._plan_decode([7, 3, 9], lens, [[11], [12], [13]], False)
+    assert unpadded.batch_size == 3 and unpadded.real_seqs == 3
+    assert (plan.seq_block_size, plan.num_seq_blocks, plan.max_decoding_len) == \
+        (unpadded.seq_block_size, unpadded.num_seq_blocks, unpadded.max_decoding_len)
+    assert plan_batch([[1]], [0], [5], 8).real_seqs == 1     # (a plan nobody padded)
+
+
 def test_tiny_batch_projection_policy():
     """kernels/linear.py: when may a projection consume the previous projection's slabs / the attention partials itself?
     (pure host logic: shapes, packed twin, K-chunk that fits LDS; the layer additionally limits the batch to 2)."""

@@ -141,7 +141,7 @@ def build_model(args, cfg, min_blocks, batch, max_len, hip_graph):
                       max_blocks_per_seq=max(FILLER_BLOCKS_PER_SEQ, max_len // 16 + 8),
                       max_batch_size=batch, max_tokens_in_batch=batch * min(max_len, 8192),
                       dtype=args.dtype, fuse_qkv=args.fuse_qkv, use_hip_graph=hip_graph,
-                      use_skinny_gemm=args.skinny_gemm, tuning=dict(fuse_splitk_consumers=args.splitk_fusion, rows_decode=args.rows_decode),
+                      use_skinny_gemm=args.skinny_gemm, tuning=dict(fuse_splitk_consumers=args.splitk_fusion, rows_decode=getattr(args, "rows_decode", True)),
                       pack_decode_weights=getattr(args, "packed_weights", True))
     model = LlamaModel(ec)
     model.load_weights()

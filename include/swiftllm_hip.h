@@ -85,6 +85,17 @@ int swl_store_kv_prefill(void *k_cache, void *v_cache, const void *k, const void
                          int32_t head_dim, int32_t max_blocks_per_seq, int64_t k_tok_stride,
                          int64_t v_tok_stride, int32_t dtype, swl_stream_t stream);
 
+/* Prefill fusion: swl_rotary on the prefill tokens' q and k (rotary_emb.py:7-42) + swl_store_kv_prefill
+ * (kvcache_mgmt.py:10-48) in ONE pass over k — transformer_layer.py:62-77 for the prefill sequences of a forward. q and k
+ * are rotated in place (k is also what the prefill attention reads), the rotated k and v go into the pools. pos_idx: rope
+ * table row per token (NULL: the token's index inside its sequence). Bit-identical to the two calls it replaces. */
+int swl_rotary_store_kv_prefill(void *q, void *k, const void *v, const void *cos_table, const void *sin_table,
+                                const int32_t *pos_idx, void *k_cache, void *v_cache, const int32_t *block_table,
+                                const int32_t *seq_ids, const int32_t *start_locs, const int32_t *seq_lens,
+                                int32_t num_prefill_seqs, int32_t max_prefill_len, int32_t cur_layer, int32_t num_layers,
+                                int32_t num_q_heads, int32_t num_kv_heads, int32_t block_size, int32_t head_dim,
+                                int32_t max_blocks_per_seq, int64_t q_tok_stride, int64_t k_tok_stride,
+                                int64_t v_tok_stride, int32_t dtype, swl_stream_t stream);
 /* reference: kvcache_mgmt.py:50-79 (_fwd_kvcache_mgmt_decoding_kernel), launcher :111-122
  * For decoding seq i (length len_i INCLUDING the new token): token i of k/v goes to slot
  * (block_table[seq_id, (len-1)/bs], (len-1)%bs). */
@@ -254,8 +265,8 @@ int swl_gemm_skinny_packed_partial(float *slabs, size_t slabs_bytes, const void 
 int swl_gemm_skinny_packed_silu_gate(void *out, const void *x, const void *w_up_gate_packed, int32_t M, int32_t I,
                                      int32_t K, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype,
                                      swl_stream_t stream);
-/* Medium batches on a packed weight: out[M, N] = x . W^T for 32 < M <= 128 tokens (valid for any M <= 128); 2 or 4
- * blocks of 32 tokens share every weight fragment. workspace >= k_splits * M * N * 4 bytes when K is split
+/* Medium batches on a packed weight: out[M, N] = x . W^T for 32 < M <= 64 tokens (valid for any M <= 64); 2 blocks of
+ * 32 tokens share every weight fragment (65..256 tokens: swl_gemm_packed_wide below). workspace >= k_splits * M * N * 4 bytes when K is split
  * (k_splits = 0: library's choice; 16 * M * N * 4 bytes cover any). */
 int swl_gemm_packed_mid(void *out, const void *x, const void *w_packed, void *workspace, size_t workspace_bytes,
                         int32_t M, int32_t N, int32_t K, int64_t x_row_stride, int64_t out_row_stride,

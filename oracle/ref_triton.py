@@ -274,8 +274,21 @@ def cmd_forward(args):
     batch = max(len(s["seq_ids"]) for s in job["steps"])
     pad_max = max([int(v.get("pad", 0)) for v in variants] + [0])
     model = _build_model(swiftllm, job["config"], job["model_path"], False, batch + pad_max, job["max_len"], job["num_blocks"])
-    plan = dict(seq_block_size=None)
+    plan = dict(seq_block_size=job.get("seq_block_size"))      # (a job may pin the split width of its BASE run too)
     inner_forward = model._forward
+    # `dump_residual_steps`: at these scripted steps, the residual stream after every transformer layer (residual_buf + the
+    # layer's FFN output, fp32, [layers, tokens, hidden]) goes to <out>.residual.pt — the per-layer attribution diagnostic
+    # of tests/test_gpu_parity_attribution.py. Recording only: the layer's own forward is called unchanged.
+    dump_steps = set(job.get("dump_residual_steps") or [])
+    residual_log, cur_step = {}, [None]
+    if dump_steps:
+        for layer in model.transformer_layers:
+            def hooked(input_embds, residual_buf, *a, _orig=layer.forward, **kw):
+                out = _orig(input_embds, residual_buf, *a, **kw)
+                if cur_step[0] in dump_steps:
+                    residual_log.setdefault(cur_step[0], []).append((residual_buf.float() + out.float()).cpu())
+                return out
+            layer.forward = hooked
 
     def planned_forward(ids, st):
         sbs = plan["seq_block_size"]
@@ -325,7 +338,9 @@ def cmd_forward(args):
                     ids = list(ids) + [[t] for t in dummy_toks]
                     dec_lens = dec_lens + dummy_lens
                 seq_ids = seq_ids + dummy_ids
+            cur_step[0] = si if forced is None and split == 1 and not reverse and not pad and subset is None else None
             t, lg = run_step(ids, seq_ids, dec_lens, split, reverse)
+            cur_step[0] = None
             if pad:
                 dummy_toks = t[-pad:]
                 t, lg = t[:-pad], lg[:-pad]
@@ -341,6 +356,8 @@ def cmd_forward(args):
         res.append(dict(tokens=t, logits=None if not want else (lg.cpu() if keep == "storage" else lg.float().cpu())))
     torch.save(res, args.out)
     print(f"reference forward: {len(res)} steps -> {args.out}")
+    if residual_log:
+        torch.save({s: torch.stack(v) for s, v in residual_log.items()}, args.out + ".residual.pt")
 
     if variants:
         # the base run's own decisiveness: smallest top-2 gap over all rows

@@ -37,6 +37,8 @@ SIGNATURES = {
                              _I32, _I32, _I64, _I64, _I32, _P],
     "swl_store_kv_decode": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32,
                             _I64, _I64, _I32, _P],
+    "swl_rotary_store_kv_prefill": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32,
+                                    _I32, _I32, _I32, _I64, _I64, _I64, _I32, _P],
     "swl_silu_mul": [_P, _I64, _I32, _I32, _P],
     "swl_argmax": [_P, _P, _P, ctypes.c_size_t, _I64, _I32, _I64, _I32, _P],
     "swl_paged_attn_decode": [_P, _P, _P, _P, _P, _P, _P, _P, _F32, _I32, _I32, _I32, _I32, _I32,

@@ -6,7 +6,7 @@
 //        PACKED = false      ... row-major W through a wave-private LDS transpose
 //        PACKED = true       ... W pre-packed in MFMA-fragment order (swl_gemm_pack_weight): global -> VGPR -> MFMA;
 //                                the default decode path (EngineConfig.pack_decode_weights)
-//   gemm_packed_mt_kernel    packed W, 2 or 4 blocks of 32 tokens per weight fragment (32 < M <= 128)
+//   gemm_packed_mt_kernel    packed W, 2 blocks of 32 tokens per weight fragment (32 < M <= 64)
 //   splitk_reduce_kernel, pack_weight_kernel
 //
 // out[M, N] = x[M, K] . W[N, K]^T  — the shape of every projection of a decode step
@@ -924,7 +924,7 @@ extern "C" int swl_gemm_skinny_packed_silu_gate_nf(void *out, const void *x, con
     return swl::check_launch();
 }
 
-// ---- medium batches on packed weights: 32 < M <= 128 -----------------------------------------------------------
+// ---- medium batches on packed weights: 32 < M <= 64 ------------------------------------------------------------
 // With W arriving in fragment order there is no LDS traffic for W at all, so MT = 2 or 4 blocks of 32 tokens can
 // share every W fragment at the price of MT x-fragment reads per k-step (1 LDS read per MFMA; the row-major attempt
 // paid 1 + MT reads plus the W round trip and was LDS bound: profiles/r01e_gemm_mtile_experiment.jsonl). hipBLASLt
@@ -1097,6 +1097,10 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void gemm_packed_mt_kernel(
 
 // Splits as for M <= 32 (>= 768 waves), capped so the slab traffic (2 * ks * M * N * 4 B) stays under a third of
 // the weight bytes: ks <= K / (12 * M) (measured optimum at M = 48..128: o_proj 4, down_proj 8).
+// Two blocks of 32 tokens per weight fragment: 33..64 tokens. (r01-r04 also built MT = 4 for 65..128 tokens: csrc/gemm_wide.hip
+// serves those since r04 and the routing never reached it — it was the only kernel of the library that spilled. Removed in r05.)
+constexpr int kMidMaxM = 64;
+
 static int choose_k_splits_mt(int M, int N, int K) {
     const int tiles = N / 32;
     const int cap = K / (12 * M);
@@ -1114,18 +1118,12 @@ static int run_gemm_packed_mt(T *out, const T *x, const T *wp, float *ws, size_t
     const dim3 grid((N / 32 + kGemmWaves - 1) / kGemmWaves, ks), block(kGemmWaves * 64);
     const int kc = K / ks;
     if (ks == 1 && reduce) {
-        if (M <= 64)
-            hipLaunchKernelGGL((gemm_packed_mt_kernel<T, 2, kGemmDirect>), grid, block, 0, stream, out, x, wp, M, N, K, kc, xs, os);
-        else
-            hipLaunchKernelGGL((gemm_packed_mt_kernel<T, 4, kGemmDirect>), grid, block, 0, stream, out, x, wp, M, N, K, kc, xs, os);
+        hipLaunchKernelGGL((gemm_packed_mt_kernel<T, 2, kGemmDirect>), grid, block, 0, stream, out, x, wp, M, N, K, kc, xs, os);
         return check_launch();
     }
     if (!ws || ws_bytes < static_cast<size_t>(ks) * M * N * sizeof(float)) return SWL_ERR_BAD_ARG;
     const int64_t n64 = N;
-    if (M <= 64)
-        hipLaunchKernelGGL((gemm_packed_mt_kernel<T, 2, kGemmPartial>), grid, block, 0, stream, ws, x, wp, M, N, K, kc, xs, n64);
-    else
-        hipLaunchKernelGGL((gemm_packed_mt_kernel<T, 4, kGemmPartial>), grid, block, 0, stream, ws, x, wp, M, N, K, kc, xs, n64);
+    hipLaunchKernelGGL((gemm_packed_mt_kernel<T, 2, kGemmPartial>), grid, block, 0, stream, ws, x, wp, M, N, K, kc, xs, n64);
     if (!reduce) return check_launch();
     const int64_t items = static_cast<int64_t>(M) * (N / 4);
     hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(static_cast<unsigned>((items + 255) / 256)), dim3(256), 0,
@@ -1135,7 +1133,7 @@ static int run_gemm_packed_mt(T *out, const T *x, const T *wp, float *ws, size_t
 
 } // namespace swl
 
-/* out[M, N] = x . W^T for 32 < M <= 128 tokens (any M <= 128 is valid) on a weight packed by swl_gemm_pack_weight.
+/* out[M, N] = x . W^T for 32 < M <= 64 tokens (any M <= 64 is valid) on a weight packed by swl_gemm_pack_weight.
  * N % 32 == 0, K % 128 == 0. workspace >= k_splits * M * N * 4 bytes when K is split (k_splits = 0: library's
  * choice; 16 * M * N * 4 bytes cover any). */
 extern "C" int swl_gemm_packed_mid(void *out, const void *x, const void *w_packed, void *workspace,
@@ -1144,7 +1142,7 @@ extern "C" int swl_gemm_packed_mid(void *out, const void *x, const void *w_packe
     if (M < 0 || N <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
     if (M == 0) return SWL_OK;
     if (!out || !x || !w_packed) return SWL_ERR_BAD_ARG;
-    if (M > 128 || (N & 31) || (K & (swl::kKT - 1))) return SWL_ERR_UNSUPPORTED;
+    if (M > swl::kMidMaxM || (N & 31) || (K & (swl::kKT - 1))) return SWL_ERR_UNSUPPORTED;
     if (x_row_stride < K || out_row_stride < N || (x_row_stride & 7) || (out_row_stride & 3)) return SWL_ERR_BAD_ARG;
     if (!swl::aligned16(x) || !swl::aligned16(w_packed) || (reinterpret_cast<uintptr_t>(out) & 7u) ||
         (workspace && !swl::aligned16(workspace)))
@@ -1160,7 +1158,7 @@ extern "C" int swl_gemm_packed_mid(void *out, const void *x, const void *w_packe
 
 /* The split count swl_gemm_packed_mid picks for k_splits = 0 (0 = shape unsupported). */
 extern "C" int swl_gemm_packed_mid_choose_splits(int32_t M, int32_t N, int32_t K) {
-    if (M <= 0 || M > 128 || N <= 0 || K <= 0 || (N & 31) || (K & (swl::kKT - 1))) return 0;
+    if (M <= 0 || M > swl::kMidMaxM || N <= 0 || K <= 0 || (N & 31) || (K & (swl::kKT - 1))) return 0;
     return swl::choose_k_splits_mt(M, N, K);
 }
 
@@ -1173,7 +1171,7 @@ extern "C" int swl_gemm_packed_mid_partial(float *slabs, size_t slabs_bytes, con
     if (M == 0) return SWL_OK;
     if (!slabs || !x || !w_packed || k_splits < 1 || k_splits > 16 || (k_splits & (k_splits - 1)))
         return SWL_ERR_BAD_ARG;
-    if (M > 128 || (N & 31) || (K & (swl::kKT - 1))) return SWL_ERR_UNSUPPORTED;
+    if (M > swl::kMidMaxM || (N & 31) || (K & (swl::kKT - 1))) return SWL_ERR_UNSUPPORTED;
     if (x_row_stride < K || (x_row_stride & 7) || !swl::aligned16(x) || !swl::aligned16(w_packed) ||
         !swl::aligned16(slabs))
         return SWL_ERR_BAD_ARG;
@@ -1184,7 +1182,7 @@ extern "C" int swl_gemm_packed_mid_partial(float *slabs, size_t slabs_bytes, con
     });
 }
 
-/* out[M, I] = up * silu(gate) of x . [up ; gate]^T for 32 < M <= 128 tokens on a packed weight (the medium-batch
+/* out[M, I] = up * silu(gate) of x . [up ; gate]^T for 32 < M <= 64 tokens on a packed weight (the medium-batch
  * twin of swl_gemm_skinny_packed_silu_gate; same rounding points as linear + silu_and_mul). I % 32 == 0. */
 extern "C" int swl_gemm_packed_mid_silu_gate(void *out, const void *x, const void *w_up_gate_packed, int32_t M,
                                              int32_t I, int32_t K, int64_t x_row_stride, int64_t out_row_stride,
@@ -1192,21 +1190,16 @@ extern "C" int swl_gemm_packed_mid_silu_gate(void *out, const void *x, const voi
     if (M < 0 || I <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
     if (M == 0) return SWL_OK;
     if (!out || !x || !w_up_gate_packed) return SWL_ERR_BAD_ARG;
-    if (M > 128 || (I & 31) || (K & (swl::kKT - 1))) return SWL_ERR_UNSUPPORTED;
+    if (M > swl::kMidMaxM || (I & 31) || (K & (swl::kKT - 1))) return SWL_ERR_UNSUPPORTED;
     if (x_row_stride < K || out_row_stride < I || (x_row_stride & 7) || (out_row_stride & 3)) return SWL_ERR_BAD_ARG;
     if (!swl::aligned16(x) || !swl::aligned16(w_up_gate_packed) || (reinterpret_cast<uintptr_t>(out) & 7u))
         return SWL_ERR_BAD_ARG;
     const dim3 grid((I / 32 + 1) / 2, 1), block(swl::kGemmWaves * 64);
     hipStream_t s = static_cast<hipStream_t>(stream);
     SWL_DISPATCH_DTYPE(dtype, T, {
-        if (M <= 64)
-            hipLaunchKernelGGL((swl::gemm_packed_mt_kernel<T, 2, swl::kGemmSiluGate>), grid, block, 0, s, out,
-                               static_cast<const T *>(x), static_cast<const T *>(w_up_gate_packed), M, I, K, K,
-                               x_row_stride, out_row_stride);
-        else
-            hipLaunchKernelGGL((swl::gemm_packed_mt_kernel<T, 4, swl::kGemmSiluGate>), grid, block, 0, s, out,
-                               static_cast<const T *>(x), static_cast<const T *>(w_up_gate_packed), M, I, K, K,
-                               x_row_stride, out_row_stride);
+        hipLaunchKernelGGL((swl::gemm_packed_mt_kernel<T, 2, swl::kGemmSiluGate>), grid, block, 0, s, out,
+                           static_cast<const T *>(x), static_cast<const T *>(w_up_gate_packed), M, I, K, K,
+                           x_row_stride, out_row_stride);
     });
     return swl::check_launch();
 }

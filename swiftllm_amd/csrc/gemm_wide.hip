@@ -18,8 +18,11 @@
 //     one tile ahead, one barrier per K-tile (32 MFMAs per wave between barriers at MT = 8);
 //   * NWV = 8 (512 threads, 256 rows of W per workgroup: x is re-read N/256 times) for wide projections, NWV = 4
 //     (two workgroups per CU, x re-read N/128 times but twice the workgroups) for narrow ones; K is split across
-//     workgroups into fp32 slabs only as far as the slab traffic (2 * ks * M * N * 4 bytes) stays below the weight
-//     bytes — gemm_wide_plan();
+//     workgroups into fp32 slabs as far as that keeps <= 256 workgroups and K-chunks of >= 16 (8 beyond 128 tokens)
+//     K-tiles — gemm_wide_plan(), the measured optimum of profiles/r04d_gemm_wide_micro.jsonl. (r04's header claimed a
+//     cap "slab traffic 2 * ks * M * N * 4 bytes below the weight bytes"; the plan never enforced one and should not:
+//     o_proj at 256 tokens runs ks = 8 — 64 MiB of slab traffic for 32 MiB of weights — in 30.1 us, 35.7 us at the
+//     ks = 4 such a cap would force: filling the chip beats the L2-resident slab round trip. ADVICE r04.)
 //   * SiLU-gate mode: the first half of the waves own `up` tiles, the second half the `gate` tiles of the same
 //     columns; activated gate tiles change hands through the (then idle) x buffers, MT/2 token blocks per round;
 //     same rounding points as linear -> silu_and_mul_inplace (silu_and_mul.py:16-23).

@@ -56,7 +56,7 @@ class EngineConfig:
 
     # Internal switches (all on): set through `tuning`, read by the layer code as plain attributes.
     TUNING_DEFAULTS = dict(
-        fuse_rope_kvstore=True,         # pure-decode batches: rotary + decode KV store in one launch instead of two
+        fuse_rope_kvstore=True,         # rotary + KV store in one launch (decode tokens; r05: prompt tokens too, one pass over k)
         fuse_splitk_consumers=True,     # the next kernel sums a projection's split-K slabs (no reduce launches)
         fuse_rope_into_attention=True,  # ... and rotary + KV store run in the paged-attention kernel's prologue
         # apply the RMSNorm scale AFTER the projection that consumes the normalised activations (a per-token scalar), so the

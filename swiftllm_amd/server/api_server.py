@@ -77,7 +77,10 @@ def build_app(engine: Engine) -> fastapi.FastAPI:
         finally:
             state["outstanding_tokens"] -= cost
         if request.error is not None:
-            return JSONResponse({"error": request.error}, status_code=400)
+            # a request the engine can never serve is the client's error (400); an engine whose model thread is gone is
+            # the server's (503: a router in front retries on another replica)
+            dead = getattr(engine, "_dead", None) is not None and request.error == engine._dead
+            return JSONResponse({"error": request.error}, status_code=503 if dead else 400)
         if want_text:
             return JSONResponse({"output": await engine.tokenization_engine.decode(token_ids)})
         return JSONResponse({"output_token_ids": token_ids})

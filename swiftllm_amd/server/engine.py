@@ -51,6 +51,7 @@ class Engine:
         self._model_thread: Optional[threading.Thread] = None
         # event-loop thread only: requests somebody may still be waiting on (woken with `error` set if the model thread dies)
         self._live: set = set()
+        self._dead = None               # why the model thread is gone (set by _fail_live): new requests are refused with it
 
     async def _run_on_model_async(self, func, *args, **kwargs):
         return await self.event_loop.run_in_executor(None, functools.partial(func, *args, **kwargs))
@@ -87,6 +88,11 @@ class Engine:
     # ---- request entry points -----------------------------------------------------------------------------
     def _enqueue(self, raw_request: RawRequest) -> Request:
         request = Request(raw_request)
+        if self._dead is not None:      # the model thread is gone: answer at once, nobody will ever serve this
+            request.error = self._dead
+            request.finished_event.set()
+            request.output_q.put_nowait(None)
+            return request
         self._live.add(request)         # (event-loop thread; leaves in _deliver / on rejection / in _fail_live)
         self.untokenized_raw_requests.append((request, raw_request))
         return request
@@ -127,7 +133,7 @@ class Engine:
                     req.prompt_len = len(token_ids)
             servable = []
             for req, _ in pending:
-                req.error = self.scheduler.why_unservable(req)      # (reads the engine's limits only)
+                req.error = self._dead or self.scheduler.why_unservable(req)      # (reads the engine's limits only)
                 if req.error is None:
                     servable.append(req)
                 else:           # answer at once: waiters wake up with no tokens, streams end
@@ -149,8 +155,10 @@ class Engine:
     def _fail_live(self, why: str):
         """The model thread is gone: wake every caller still waiting (event-loop thread). `add_request_and_wait` returns
         with what was generated so far and `request.error` set; streams end."""
+        self._dead = why                # from now on _enqueue and the tokenize loop refuse instead of queueing
         live, self._live = list(self._live), set()
-        for req in live:
+        pending, self.untokenized_raw_requests = self.untokenized_raw_requests, []
+        for req in live + [r for r, _ in pending]:
             req.error = req.error or why
             req.finished_event.set()
             req.output_q.put_nowait(None)

@@ -22,6 +22,7 @@ import torch
 import torch.nn.functional as F
 
 from swiftllm_amd import _hip
+from . import route_tune
 
 _SKINNY_MAX_M = 32
 _workspaces = {}    # device -> persistent fp32 split-K scratch (fixed address: hipGraph replays use it)
@@ -95,19 +96,17 @@ class SplitKPartials:
         return out
 
 
-_MID_MAX_M = 128
+_MID_MAX_M = 64
 
 
 def _mid_ok(a: torch.Tensor, w: torch.Tensor) -> bool:
-    """Medium decode batches (32 < M <= 128) on a packed weight: 2 or 4 blocks of 32 tokens share every weight
-    fragment (swl_gemm_packed_mid). Measured against hipBLASLt (tools/gemm_micro.py --m 48/64/128): 20-30 % faster
-    over a layer up to M = 64; above that only where K >> N (down_proj: 38 vs 75 us), so the others stay on BLAS."""
+    """Medium decode batches (32 < M <= 64) on a packed weight: 2 blocks of 32 tokens share every weight fragment
+    (swl_gemm_packed_mid). Measured against hipBLASLt (tools/gemm_micro.py --m 48/64): 20-30 % faster over a layer.
+    (65..256 tokens: `_wide_ok`, csrc/gemm_wide.hip.)"""
     m = a.shape[0] if a.dim() == 2 else 0
     if not (_SKINNY_MAX_M < m <= _MID_MAX_M) or _packed_of(w) is None:
         return False
-    n, k = w.shape
-    return (a.is_cuda and a.dtype == w.dtype and a.stride(1) == 1 and a.stride(0) % 8 == 0
-            and (m <= 64 or k >= 2 * n))
+    return a.is_cuda and a.dtype == w.dtype and a.stride(1) == 1 and a.stride(0) % 8 == 0
 
 
 _WIDE_MAX_M = 256
@@ -116,44 +115,49 @@ _WIDE_MAX_M = 256
 def _wide_ok(a: torch.Tensor, w: torch.Tensor) -> bool:
     """Large decode batches (64 < M <= 256) on a packed weight: swl_gemm_packed_wide (csrc/gemm_wide.hip) — up to 8 blocks
     of 32 tokens share every weight fragment, x^T shared by the workgroup through LDS. Which projections it serves is a
-    measured policy (`_wide_wins`, tools/gemm_wide_micro.py against hipBLASLt on MI355X)."""
+    measured policy: kernels/route_tune.py (the r04 table for the shapes it was measured on, a one-off measurement on this
+    device for any other)."""
     m = a.shape[0] if a.dim() == 2 else 0
     if not (64 < m <= _WIDE_MAX_M) or _packed_of(w) is None:
         return False
     n, k = w.shape
-    return (a.is_cuda and a.dtype == w.dtype and a.stride(1) == 1 and a.stride(0) % 8 == 0 and k % 64 == 0 and n % 32 == 0
-            and m * _row_stride(a) < (1 << 31) and _wide_wins(m, n, k))
+    if not (a.is_cuda and a.dtype == w.dtype and a.stride(1) == 1 and a.stride(0) % 8 == 0 and k % 64 == 0 and n % 32 == 0
+            and m * _row_stride(a) < (1 << 31)):
+        return False
+
+    def ours():
+        out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+        need = _hip.load().swl_gemm_packed_wide_workspace_bytes(m, n, k)
+        ws = _workspace(a.device, need) if need else None
+        _hip.call("swl_gemm_packed_wide", _hip.ptr(out), _hip.ptr(a), _hip.ptr(_packed_of(w)), _hip.ptr(ws),
+                  ws.numel() * 4 if ws is not None else 0, m, n, k, _row_stride(a), n, 0, 0, _hip.dtype_code(a.dtype),
+                  _hip.stream())
+    return route_tune.decide(m, n, k, a.dtype, a.device, False, ours, lambda: F.linear(a, w))
 
 
 def _wide_silu_ok(a: torch.Tensor, w: torch.Tensor) -> bool:
     m = a.shape[0] if a.dim() == 2 else 0
     if not (64 < m <= _WIDE_MAX_M) or _packed_of(w) is None or w.shape[0] % 64:
         return False
-    return (a.is_cuda and a.dtype == w.dtype and a.stride(1) == 1 and a.stride(0) % 8 == 0 and w.shape[1] % 64 == 0
-            and m * _row_stride(a) < (1 << 31) and _wide_silu_wins(m))
-
-
-def _wide_wins(m: int, n: int, k: int) -> bool:
-    """Where the wide kernel beats (or ties) hipBLASLt — profiles/r04c_ / r04d_gemm_wide_micro.jsonl, Llama-3-8B widths, bf16,
-    MI355X, us ours / library at M = 96, 128, 160, 192, 224, 256:
-        down (K >= 2N)   33/63  34/75  43/85  44/104  52/60  54/63      -> always
-        qkv  (N = 6144)  23/23  25/26  32/29  32/34   37/37  37/40      -> except (128, 160]
-        o    (N = 4096)  20/20  21/22  26/24  26/29   29/21  30/21      -> up to 128 and (160, 192]
-    (the library's time is far from monotone in M: its 160-token kernels are good, its 192-token ones are not). The plain
-    up/gate projection only ties (53 / 54 at 128) and loses beyond; its SiLU-gate form is decided in `_wide_silu_wins`."""
-    if k >= 2 * n:
-        return True
-    if n > 8192:
+    if not (a.is_cuda and a.dtype == w.dtype and a.stride(1) == 1 and a.stride(0) % 8 == 0 and w.shape[1] % 64 == 0
+            and m * _row_stride(a) < (1 << 31)):
         return False
-    if m <= 128 or 160 < m <= 192:
-        return True
-    return m > 192 and n > 4096
+    n2, k = w.shape
+
+    def ours():
+        out = torch.empty((m, n2 // 2), dtype=a.dtype, device=a.device)
+        _hip.call("swl_gemm_packed_wide_silu_gate", _hip.ptr(out), _hip.ptr(a), _hip.ptr(_packed_of(w)), m, n2 // 2, k,
+                  _row_stride(a), n2 // 2, 0, _hip.dtype_code(a.dtype), _hip.stream())
+
+    def library():
+        r = F.linear(a, w)
+        _hip.call("swl_silu_mul", _hip.ptr(r), m, n2 // 2, _hip.dtype_code(a.dtype), _hip.stream())
+    return route_tune.decide(m, n2, k, a.dtype, a.device, True, ours, library)
 
 
-def _wide_silu_wins(m: int) -> bool:
-    """up/gate projection + SiLU-gate in one launch against the library GEMM + silu_and_mul: 53.5 / 63.3 us at 128 tokens,
-    60.0 / 62.5 at 96; 88 / 73 at 192 (six token blocks per fragment leave too few waves per CU): up to 128 tokens."""
-    return m <= 128
+# (the r04 names, kept for tests/test_host_logic.py: the measured table itself)
+_wide_wins = route_tune.table_wide_wins
+_wide_silu_wins = route_tune.table_wide_silu_wins
 
 
 def linear(a: torch.Tensor, w: torch.Tensor, skinny: bool = False) -> torch.Tensor:
@@ -243,7 +247,7 @@ def linear_splitk(a: torch.Tensor, w: torch.Tensor, always: bool = False):
                       m, n, k, _row_stride(a), 0, ks, _hip.dtype_code(a.dtype), _hip.stream())
             return SplitKPartials(ws, ks, m, n, a.dtype)
         return linear(a, w, skinny=True)
-    if _mid_ok(a, w) and a.shape[0] <= 64:      # medium batch on a packed weight: same contract, own kernel
+    if _mid_ok(a, w):                           # medium batch on a packed weight: same contract, own kernel
         m, k = a.shape
         n = w.shape[0]
         ks = _hip.load().swl_gemm_packed_mid_choose_splits(m, n, k)
@@ -294,7 +298,7 @@ def linear_silu_gate(a: torch.Tensor, w_up_gate: torch.Tensor, row_scale=None):
         _hip.call("swl_gemm_packed_wide_silu_gate", _hip.ptr(out), _hip.ptr(a), _hip.ptr(_packed_of(w_up_gate)), m, inter, k,
                   _row_stride(a), inter, 0, _hip.dtype_code(a.dtype), _hip.stream())
         return out
-    if _mid_ok(a, w_up_gate) and a.shape[0] <= 64 and w_up_gate.shape[0] % 64 == 0:   # medium batch, packed weight
+    if _mid_ok(a, w_up_gate) and w_up_gate.shape[0] % 64 == 0:   # medium batch, packed weight
         m, k = a.shape
         inter = w_up_gate.shape[0] // 2
         out = torch.empty((m, inter), dtype=a.dtype, device=a.device)

@@ -53,6 +53,35 @@ def rotary_embedding_and_store_kvcache_decode(q: torch.Tensor, k: torch.Tensor, 
               _hip.dtype_code(q.dtype), _hip.stream())
 
 
+def rotary_embedding_and_store_kvcache_prefill(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                                               k_cache: torch.Tensor, v_cache: torch.Tensor,
+                                               block_table: torch.Tensor, model_config,
+                                               engine_config, infer_state, cur_layer: int):
+    """Batches with prefill sequences: rotary on q, k and the KV store in ONE pass over k for the prompt tokens
+    (csrc/kvcache.hip: rotary_store_prefill_kernel) — and, when decoding sequences ride along (SARATHI), the fused decode
+    launch for their tokens. = rotary_embedding_inplace + store_kvcache of the reference's transformer_layer.py:62-77,
+    bit-identical. Needs `infer_state.position_indices`."""
+    _hip.require_gpu_tensor(q, "q")
+    st = infer_state
+    assert st.num_prefill_seqs > 0 and st.position_indices is not None
+    assert k_cache.is_contiguous() and v_cache.is_contiguous() and block_table.is_contiguous()
+    qs, ks, vs = token_stride(q, "q"), token_stride(k, "k"), token_stride(v, "v")
+    code, stream = _hip.dtype_code(q.dtype), _hip.stream()
+    _hip.call("swl_rotary_store_kv_prefill", _hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(st.position_cos),
+              _hip.ptr(st.position_sin), _hip.ptr(st.position_indices), _hip.ptr(k_cache), _hip.ptr(v_cache),
+              _hip.ptr(block_table), _hip.ptr(st.seq_ids), _hip.ptr(st.prefill_seq_start_locs),
+              _hip.ptr(st.prefill_seq_lens), st.num_prefill_seqs, st.max_prefill_len, cur_layer, model_config.num_layers,
+              q.shape[1], k.shape[1], engine_config.block_size, q.shape[2], block_table.shape[1], qs, ks, vs, code, stream)
+    nd = st.num_decoding_seqs
+    if nd > 0:
+        p = st.num_prefill_tokens
+        _hip.call("swl_rotary_store_kv_decode", _hip.ptr(q[p:]), _hip.ptr(k[p:]), _hip.ptr(v[p:]),
+                  _hip.ptr(st.position_cos), _hip.ptr(st.position_sin), _hip.ptr(st.position_indices[p:]),
+                  _hip.ptr(k_cache), _hip.ptr(v_cache), _hip.ptr(block_table), _hip.ptr(st.seq_ids[st.num_prefill_seqs:]),
+                  _hip.ptr(st.decoding_seq_lens), nd, q.shape[1], k.shape[1], q.shape[2], cur_layer,
+                  model_config.num_layers, engine_config.block_size, block_table.shape[1], qs, ks, vs, code, stream)
+
+
 def rotary_embedding_and_store_kvcache_decode_from_splitk(partials, k_cache: torch.Tensor,
                                                           v_cache: torch.Tensor, block_table: torch.Tensor,
                                                           model_config, engine_config, infer_state,

@@ -42,7 +42,8 @@ from ..kernels.rmsnorm import RowScalePending
 from ..kernels.rmsnorm import (add_scale_from_splitk, deferred_norm_ok, fused_add_rmsnorm_inplace,
                                fused_add_rmsnorm_from_splitk)
 from ..kernels.rotary_emb import (rotary_embedding_inplace, rotary_embedding_and_store_kvcache_decode,
-                                  rotary_embedding_and_store_kvcache_decode_from_splitk)
+                                  rotary_embedding_and_store_kvcache_decode_from_splitk,
+                                  rotary_embedding_and_store_kvcache_prefill)
 from ..kernels.kvcache_mgmt import store_kvcache
 from ..kernels.prefill_attn import prefill_attention
 from ..kernels.paged_attn import paged_attention, paged_attention_from_qkv_splitk
@@ -227,6 +228,11 @@ class LlamaTransformerLayer:
             if fused_rope_store:
                 rotary_embedding_and_store_kvcache_decode(q, k, v, k_cache, v_cache, block_table, cfg,
                                                           ecfg, st, self.layer_id)
+            elif (st.num_prefill_seqs > 0 and not st.ignore_kvcache and st.position_indices is not None
+                  and getattr(ecfg, "fuse_rope_kvstore", False)):
+                # prompt tokens: rotary + KV store in one pass over k (r05); riding decodes: their fused launch
+                rotary_embedding_and_store_kvcache_prefill(q, k, v, k_cache, v_cache, block_table, cfg, ecfg, st,
+                                                           self.layer_id)
             else:
                 rotary_embedding_inplace(q, k, st)
                 if not st.ignore_kvcache:

@@ -177,12 +177,52 @@ class LlamaModel:
         # split-K scratch. The eager prefill peak above does not contain it.
         graph_bytes = 0
         if getattr(ecfg, "use_hip_graph", False):
-            cfg = self.model_config
-            b = ecfg.max_batch_size
-            graph_bytes = (b * cfg.vocab_size * 8 + b * (cfg.hidden_size + cfg.ffn_inter_dim) * 64 + (64 << 20))
+            graph_bytes = self._measure_decode_graph_bytes()
+            free_memory, _ = torch.cuda.mem_get_info()      # (the measurement may have grown the regular pool as well)
+            peak_memory = max(peak_memory, total_memory - free_memory)
         num_blocks = math.floor((usable - peak_memory - table_bytes - graph_bytes) / block_bytes)
         torch.cuda.empty_cache()
         return max(num_blocks, 0)
+
+    def _measure_decode_graph_bytes(self) -> int:
+        """What the private memory pool of the decode hipGraphs will hold: MEASURED (r03-r04 used a formula) as
+        the allocator's high-water mark over one eager pure-decode forward at max_batch_size on a throw-away KV pool of one
+        block per sequence — a capture allocates what the eager forward allocates, into its own pool, and all captures share
+        ONE pool (_forward_decode_graph), so the largest batch sets its size. 25 % + 16 MiB on top for the allocator's
+        rounding. Falls back to the r04 formula when the throw-away pool cannot be built."""
+        cfg, ecfg = self.model_config, self.engine_config
+        b = int(ecfg.max_batch_size)
+        formula = b * cfg.vocab_size * 8 + b * (cfg.hidden_size + cfg.ffn_inter_dim) * 64 + (64 << 20)
+        if b <= 0 or b > ecfg.max_seqs_in_block_table:
+            return formula
+        saved = (self.k_cache, self.v_cache, self.gpu_block_manager, self.cpu_block_manager, ecfg.use_hip_graph)
+        try:
+            shape = (b, cfg.num_layers, cfg.num_kv_heads, ecfg.block_size, cfg.head_dim)
+            self.k_cache = torch.zeros(shape, dtype=self.dtype, device=self.device)
+            self.v_cache = torch.zeros(shape, dtype=self.dtype, device=self.device)
+            self.gpu_block_manager = BlockManager("GPU", b, ecfg.max_seqs_in_block_table, ecfg.max_blocks_per_seq,
+                                                  ecfg.block_size, self.device)
+            ecfg.use_hip_graph = False
+            self.forward([[0]] * b, list(range(b)), [1] * b)        # (also sizes the persistent split-K workspace)
+            torch.cuda.synchronize()
+            self.gpu_block_manager.free_blocks_for_seqs(list(range(b)))
+            base = torch.cuda.memory_allocated()
+            torch.cuda.reset_peak_memory_stats()
+            self.forward([[0]] * b, list(range(b)), [1] * b)
+            torch.cuda.synchronize()
+            peak = torch.cuda.max_memory_allocated() - base
+            measured = int(peak * 1.25) + (16 << 20)
+            print(f"[Model.profile] decode activations at batch {b}: {peak / 2**20:.1f} MiB "
+                  f"(hipGraph pool reserve {measured / 2**20:.1f} MiB; r04 formula: {formula / 2**20:.1f} MiB)")
+            return measured
+        except Exception as exc:     # noqa: BLE001 — sizing aid only: any failure falls back to the formula
+            print(f"[Model.profile] decode-pool measurement failed ({type(exc).__name__}: {exc}); using the formula")
+            return formula
+        finally:
+            self.k_cache, self.v_cache, self.gpu_block_manager, self.cpu_block_manager, ecfg.use_hip_graph = saved
+            self._lookahead = None
+            self._decode_graphs.clear()
+            torch.cuda.empty_cache()
 
     @torch.inference_mode()
     def init_kvcache_and_swap(self, num_blocks: int):

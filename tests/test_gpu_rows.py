@@ -197,3 +197,58 @@ def test_rows_decode_path_equals_the_consumer_path(tmp_path, batch):
                 if tx != ty:
                     top2 = ref_logits[step - 1][seq].topk(2).values if step else None
                     assert top2 is not None and float(top2[0] - top2[1]) <= 8 * eps * float(top2[0].abs().clamp(min=1.0))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("H,KVH,D", [(32, 8, 128), (4, 1, 64), (8, 8, 128)])
+@pytest.mark.parametrize("n_dec", [0, 3])
+def test_fused_prefill_rotary_store_equals_the_two_kernels(dtype, H, KVH, D, n_dec):
+    """rotary_embedding_and_store_kvcache_prefill (one pass over k: csrc/kvcache.hip rotary_store_prefill_kernel, plus the
+    fused decode launch for riding decodes) against rotary_embedding_inplace + store_kvcache on the same inputs: q, k and
+    both pools bit for bit — ragged prompts (1 token, block boundaries, a partial last block), untouched pool blocks stay
+    untouched."""
+    import types
+    from swiftllm_amd.worker.kernels.rotary_emb import rotary_embedding_inplace, rotary_embedding_and_store_kvcache_prefill
+    from swiftllm_amd.worker.kernels.kvcache_mgmt import store_kvcache
+    g = gen(H + D + n_dec)
+    plens = [1, 16, 17, 40, 32]
+    dlens = [5, 33, 16][:n_dec]                       # lengths INCLUDING the new token
+    L, bs, layer, max_blocks = 2, 16, 1, 8
+    n_seqs = len(plens) + n_dec
+    T = sum(plens) + n_dec
+    need = [-(-n // bs) for n in plens + dlens]
+    num_blocks = sum(need) + 3
+    perm = torch.randperm(num_blocks, generator=g).tolist()
+    bt = torch.zeros(n_seqs + 2, max_blocks, dtype=torch.int32)
+    seq_ids = list(range(1, n_seqs + 1))              # (row 0 of the table unused)
+    it = iter(perm)
+    for sid, nb in zip(seq_ids, need):
+        for j in range(nb):
+            bt[sid, j] = next(it)
+    pos = torch.cat([torch.arange(n) for n in plens] + [torch.tensor([n - 1]) for n in dlens]).to(torch.int32)
+    table_rows = 64
+    cos = torch.randn(table_rows, D // 2, generator=g).to(dtype).cuda()
+    sin = torch.randn(table_rows, D // 2, generator=g).to(dtype).cuda()
+    q0 = torch.randn(T, H, D, generator=g).to(dtype).cuda()
+    k0 = torch.randn(T, KVH, D, generator=g).to(dtype).cuda()
+    v0 = torch.randn(T, KVH, D, generator=g).to(dtype).cuda()
+    pool0 = torch.randn(num_blocks, L, KVH, bs, D, generator=g).to(dtype).cuda()
+    pl = torch.tensor(plens, dtype=torch.int32)
+    st = types.SimpleNamespace(
+        seq_ids=torch.tensor(seq_ids, dtype=torch.int32).cuda(), num_prefill_seqs=len(plens), num_prefill_tokens=sum(plens),
+        prefill_seq_start_locs=(torch.cumsum(pl, 0, dtype=torch.int32) - pl).cuda(), prefill_seq_lens=pl.cuda(),
+        max_prefill_len=max(plens), num_decoding_seqs=n_dec,
+        decoding_seq_lens=torch.tensor(dlens, dtype=torch.int32).cuda(), position_cos=cos, position_sin=sin,
+        position_indices=pos.cuda())
+    mc = types.SimpleNamespace(num_layers=L, num_kv_heads=KVH, head_dim=D)
+    ec = types.SimpleNamespace(block_size=bs)
+    btd = bt.cuda()
+    q1, k1, v1, kc1, vc1 = q0.clone(), k0.clone(), v0.clone(), pool0.clone(), pool0.flip(0).clone()
+    rotary_embedding_inplace(q1, k1, st)
+    store_kvcache(k1, v1, kc1, vc1, btd, mc, ec, st, layer)
+    q2, k2, v2, kc2, vc2 = q0.clone(), k0.clone(), v0.clone(), pool0.clone(), pool0.flip(0).clone()
+    rotary_embedding_and_store_kvcache_prefill(q2, k2, v2, kc2, vc2, btd, mc, ec, st, layer)
+    torch.cuda.synchronize()
+    assert torch.equal(q1, q2) and torch.equal(k1, k2) and torch.equal(v1, v2)
+    assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2)
+    assert not torch.equal(kc2, pool0)                # (something was stored)

@@ -407,6 +407,40 @@ def test_decode_batch_buckets_and_inert_rows():
     assert plan_batch([[1]], [0], [5], 8).real_seqs == 1     # (a plan nobody padded)
 
 
+def test_wide_kernel_routing_measured_table_and_one_off_measurement(tmp_path, monkeypatch):
+    """kernels/route_tune.py: the r04 table answers only for the classes it was measured on (Llama-3-8B widths, bfloat16);
+    anything else is timed once (hand-written kernel taken when > 3 % faster), remembered in memory and on disk, never
+    timed inside a stream capture; SWIFTLLM_ROUTE_TUNE=table / off pin the policy."""
+    import torch
+    from swiftllm_amd.worker.kernels import route_tune as R
+    monkeypatch.setenv("SWIFTLLM_ROUTE_CACHE", str(tmp_path / "routes.json"))
+    monkeypatch.delenv("SWIFTLLM_ROUTE_TUNE", raising=False)
+    monkeypatch.setattr(R, "_cache", None)
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    boom = lambda: (_ for _ in ()).throw(AssertionError("a measured class must not be timed"))   # noqa: E731
+    assert R.decide(128, 4096, 14336, torch.bfloat16, "cpu", False, boom, boom) is True        # down: the table
+    assert R.decide(160, 4096, 4096, torch.bfloat16, "cpu", False, boom, boom) is False        # o_proj at 160: library
+    assert R.decide(192, 28672, 4096, torch.bfloat16, "cpu", True, boom, boom) is False        # SiLU-gate form > 128 tokens
+    times = iter([10.0, 12.0, 10.0, 10.2])      # ours, library | ours, library
+    calls = []
+    monkeypatch.setattr(R, "_time_us", lambda fn, iters=8, warm=2: (calls.append(fn), next(times))[1])
+    assert R.decide(100, 5120, 5120, torch.bfloat16, "cpu", False, "ours", "lib") is True      # 10 * 1.03 < 12
+    assert R.decide(128, 5120, 5120, torch.bfloat16, "cpu", False, boom, boom) is True         # same 32-token bucket: cached
+    assert R.decide(129, 5120, 5120, torch.bfloat16, "cpu", False, "ours", "lib") is False     # next bucket: a 2 % win is no win
+    assert calls == ["ours", "lib", "ours", "lib"]
+    # float16 at a measured (N, K): not the measured dtype -> timed; a kernel that refuses the shape (here: raises) = library
+    assert R.decide(100, 4096, 4096, torch.float16, "cpu", False, boom, boom) is False
+    monkeypatch.setattr(R, "_cache", None)      # a new process: the file answers
+    assert R.decide(100, 5120, 5120, torch.bfloat16, "cpu", False, boom, boom) is True
+    assert R.decide(130, 5120, 5120, torch.bfloat16, "cpu", False, boom, boom) is False
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
+    assert R.decide(100, 6144, 6144, torch.bfloat16, "cpu", False, boom, boom) is False        # capturing: never timed
+    monkeypatch.setenv("SWIFTLLM_ROUTE_TUNE", "off")
+    assert R.decide(100, 7168, 7168, torch.bfloat16, "cpu", False, boom, boom) is False
+    monkeypatch.setenv("SWIFTLLM_ROUTE_TUNE", "table")
+    assert R.decide(100, 4096, 11008, torch.float16, "cpu", False, boom, boom) is True         # K >= 2N by the table
+
+
 def test_tiny_batch_projection_policy():
     """kernels/linear.py: when may a projection consume the previous projection's slabs / the attention partials itself?
     (pure host logic: shapes, packed twin, K-chunk that fits LDS; the layer additionally limits the batch to 2)."""

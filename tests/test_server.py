@@ -572,6 +572,16 @@ def test_waiters_wake_up_when_the_model_thread_dies():
         req, toks = await asyncio.wait_for(waiter, 20)
         got = await asyncio.wait_for(streamer, 20)
         assert req.error and "boom" in req.error and len(toks) < 4 and len(got) < 4
+        # a request that arrives AFTER the model thread died is refused at once, not parked for ever ...
+        late, late_toks = await asyncio.wait_for(engine.add_request_and_wait(RawRequest("", 4, [9, 9])), 5)
+        assert late.error and "boom" in late.error and late_toks == [] and not engine._live
+        assert [o async for o in engine.add_request_and_stream(RawRequest("", 2, [7]))] == []
         with pytest.raises(RuntimeError, match="boom"):
             await asyncio.wait_for(loops, 20)
-    asyncio.run(scenario())
+        return engine
+    engine = asyncio.run(scenario())
+    # ... and the HTTP face answers 503 (the server's fault: a router retries elsewhere), not the client's 400
+    from starlette.testclient import TestClient
+    from swiftllm_amd.server.api_server import build_app
+    r = TestClient(build_app(engine)).post("/generate", json=dict(prompt_token_ids=[1, 2], output_len=2))
+    assert r.status_code == 503 and "boom" in r.json()["error"]

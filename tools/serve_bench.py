@@ -24,6 +24,9 @@ def parse():
     ap.add_argument("--rate", type=float, default=0.0, help="Poisson arrival rate (req/s); 0 = all at once")
     ap.add_argument("--modes", default="plain,piggyback")
     ap.add_argument("--kv-blocks", type=int, default=0, help="KV pool size in blocks (0 = profile_num_blocks at 0.97)")
+    ap.add_argument("--passes", type=int, default=1,
+                    help="run every mode this many times in the same process: pass 1 pays the hipGraph captures of the batch / "
+                         "split-geometry buckets it meets, later passes show the steady state (graph_captures should be 0)")
     return ap.parse_args()
 
 
@@ -53,14 +56,21 @@ async def run(model, a, piggyback):
         delays.append(t)
         if a.rate > 0:
             t += rng.expovariate(a.rate)
+    caps0, fwd0 = getattr(model, "graph_captures", 0), eng.num_forwards
     t0 = time.perf_counter()
     await asyncio.gather(*(one(p, d) for p, d in zip(prompts, delays)))
     dt = time.perf_counter() - t0
     loops.cancel()
+    caps = getattr(model, "graph_captures", 0) - caps0
+    fwds = max(1, eng.num_forwards - fwd0)
     ttft.sort(); tpot.sort()
     return {"piggyback": piggyback, "requests": a.requests, "prompt_len": a.prompt_len, "gen_len": a.gen_len,
             "rate_req_s": a.rate, "wall_s": round(dt, 3), "output_tok_s": round(a.requests * a.gen_len / dt, 1),
             "total_tok_s": round(a.requests * (a.gen_len + a.prompt_len) / dt, 1), "forwards": eng.num_forwards,
+            # every capture = one eager warm-up forward + one capture (worker/model.py: _forward_decode_graph); keyed on batch
+            # BUCKETS and split-geometry buckets since r05
+            "graph_captures": caps, "graph_captures_per_1000_forwards": round(1000.0 * caps / fwds, 2),
+            "graphs_cached": len(getattr(model, "_decode_graphs", {}) or {}),
             "ttft_ms_p50": round(ttft[len(ttft) // 2] * 1e3, 1), "ttft_ms_max": round(ttft[-1] * 1e3, 1),
             "tpot_ms_p50": round(tpot[len(tpot) // 2] * 1e3, 2) if tpot else None,
             "tpot_ms_p99": round(tpot[int(len(tpot) * 0.99)] * 1e3, 2) if tpot else None}
@@ -81,11 +91,14 @@ def main():
     model.engine_config.max_tokens_in_batch = a.max_tokens
     model.engine_config.max_batch_size = a.max_batch
     for mode in a.modes.split(","):
-        res = asyncio.run(run(model, a, mode == "piggyback"))
-        res["model"] = a.model
-        res["kv_pool_blocks"] = int(model.num_blocks)
-        res["kv_pool_gb"] = round(2 * model.k_cache.numel() * model.k_cache.element_size() / 1e9, 1)
-        print(json.dumps(res), flush=True)
+        for p in range(a.passes):
+            res = asyncio.run(run(model, a, mode == "piggyback"))
+            res["pass"] = p + 1
+            res["model"] = a.model
+            res["max_batch"] = a.max_batch
+            res["kv_pool_blocks"] = int(model.num_blocks)
+            res["kv_pool_gb"] = round(2 * model.k_cache.numel() * model.k_cache.element_size() / 1e9, 1)
+            print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":

@@ -320,7 +320,9 @@ def _pmc_traffic(name, alg_bytes, ok):
         return None, None
     with open(path, encoding="utf-8") as f:
         pmc = json.load(f)
-    return int(alg_bytes * pmc["traffic_over_algorithmic"]), f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, scaled by bytes)"
+    return (int(alg_bytes * pmc["traffic_over_algorithmic"]),
+            f"COMMITTED measurement, not taken in this run: profiles/{name} (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE in separate "
+            f"passes over this kernel at this shape), scaled by bytes")
 
 
 def attention_roofline(model, lens, iters):
@@ -395,18 +397,28 @@ def gemm_roofline(model, batch, iters):
     out = torch.empty(M, I, device=model.device, dtype=model.dtype)
     code = _hip.dtype_code(model.dtype)
     packed = all(getattr(l.up_gate_proj, "_swl_packed", None) is not None for l in layers)
-    fn = "swl_gemm_skinny_packed_silu_gate" if packed else "swl_gemm_skinny_silu_gate"
+    # the entry the decode step runs: since r05 (rows_decode, bfloat16) the SiLU-gate GEMM normalises the raw residual rows
+    # on the fly (csrc/gemm_skinny.hip NF); else the plain packed / row-major forms
+    nf = packed and getattr(ecfg, "rows_decode", False) and model.dtype == torch.bfloat16
+    fn = ("swl_gemm_skinny_packed_silu_gate_nf" if nf else "swl_gemm_skinny_packed_silu_gate") if packed else "swl_gemm_skinny_silu_gate"
     srcs = [(l.up_gate_proj._swl_packed if packed else l.up_gate_proj) for l in layers]
+    norms = [l.ffn_norm for l in layers]
 
     def launch(i):
-        _hip.call(fn, out.data_ptr(), x.data_ptr(), srcs[i % len(srcs)].data_ptr(), M, I, K, K, I, code, _hip.stream())
+        j = i % len(srcs)
+        if nf:
+            _hip.call(fn, out.data_ptr(), x.data_ptr(), norms[j].data_ptr(), mc.rms_norm_eps, srcs[j].data_ptr(), M, I, K, K, I,
+                      code, _hip.stream())
+        else:
+            _hip.call(fn, out.data_ptr(), x.data_ptr(), srcs[j].data_ptr(), M, I, K, K, I, code, _hip.stream())
     us = _event_time(launch, iters, min(iters, len(layers)))
     e = model.dtype.itemsize
     alg_bytes = 2 * I * K * e + M * K * e + M * I * e
     gbs = alg_bytes / (us * 1e-6) / 1e9
-    pmc_name = "r04_gemm_silu_packed_pmc.json" if packed else "r01e_gemm_silu_pmc.json"
+    pmc_name = ("r05_gemm_silu_nf_pmc.json" if nf else "r04_gemm_silu_packed_pmc.json") if packed else "r01e_gemm_silu_pmc.json"
     traffic, src = _pmc_traffic(pmc_name, alg_bytes, (I, K) == (14336, 4096) and model.dtype == torch.bfloat16)
-    return dict(bound="hbm", kernel="%s (gemm_skinny_ring_kernel<SiluGate%s>: up/gate projection + SiLU-gate)" % (fn, ", packed W" if packed else ""),
+    return dict(bound="hbm", kernel="%s (gemm_skinny_ring_kernel<SiluGate%s%s>: up/gate projection + SiLU-gate)" % (
+                    fn, ", packed W" if packed else "", ", norm on the fly" if nf else ""),
                 achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
                 frac_of_measured_copy=round(gbs / HBM_COPY_GBS, 4), traffic=traffic, traffic_source=src,
                 bytes_per_launch=int(alg_bytes), us_per_launch=round(us, 2), launches=iters)

@@ -132,6 +132,20 @@ def layer_mode(a):
         print(json.dumps(row), flush=True)
 
 
+def pmc_mode(a):
+    dt = torch.bfloat16
+    N, K = (a.hidden, a.hidden) if a.pmc == "o" else (a.hidden, a.inter)
+    M = int(a.m.split(",")[0])
+    g = torch.Generator(device="cuda").manual_seed(2)
+    ws = [pack_weight_ret((torch.randn(N, K, device="cuda", generator=g) * 0.02).to(dt)) for _ in range(a.copies)]
+    x = torch.randn(M, K, device="cuda", generator=g).to(dt)
+    res = torch.randn(M, N, device="cuda", generator=g).to(dt)
+    us = time_us(lambda i: linear_rows_add(x, ws[i % a.copies], res), a.iters)
+    alg = N * K * 2 + M * K * 2 + 2 * M * N * 2          # W once, x once, residual read + write
+    print(json.dumps({"kernel": f"gemm_rows_kernel<bf16> ({a.pmc}_proj + residual add)", "M": M, "N": N, "K": K, "us": round(us, 2),
+                      "algorithmic_bytes": alg, "TBps": round(alg / us / 1e6, 3)}))
+
+
 def pack_weight_ret(w):
     pack_weight(w)
     return w
@@ -146,7 +160,12 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--copies", type=int, default=6)
     ap.add_argument("--no-chain", action="store_true")
+    ap.add_argument("--pmc", default="", choices=["", "o", "down"],
+                    help="launch only swl_gemm_rows_add at this projection's shape, `--iters` times over `--copies` weights "
+                         "(for rocprofv3 --pmc passes: tools/gpu_pmc_rows.sh); prints the algorithmic bytes")
     a = ap.parse_args()
+    if a.pmc:
+        return pmc_mode(a)
     if a.layer:
         return layer_mode(a)
     dt = torch.bfloat16

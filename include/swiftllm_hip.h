@@ -347,8 +347,7 @@ int swl_decode_positions(int32_t *pos_idx, const int32_t *seq_lens, int32_t num_
  *     rstd[m] = 1/sqrt(sum_p row_ssq[p][m] / K + eps). Replaces transformer_layer.py:120-127 for decode batches.
  *   swl_paged_attn_decode_qkv_rs: swl_paged_attn_decode_qkv whose fused-qkv slab sums are scaled the same way before they
  *     are rounded, rotated and stored (transformer_layer.py:46-77 + paged_attn.py:152-222). k_splits in {1, 2, 4}.
- * ssq_parts <= 8, except swl_gemm_skinny_packed_silu_gate_rs: <= 256 (more than 8: row_ssq 16-byte aligned,
- * ssq_parts * M a multiple of 4 — the per-tile partials of swl_gemm_rows_add_scale, copied to LDS and added in order). */
+ * ssq_parts <= 8 everywhere. */
 int swl_splitk_add_scale(void *x_scaled, void *residual, const void *w, const float *slabs, int32_t k_splits,
                          float *ssq_out, int64_t num_tokens, int32_t hidden, int32_t dtype, swl_stream_t stream);
 int swl_gemm_skinny_packed_silu_gate_rs(void *out, const void *x, const void *w_up_gate_packed, const float *row_ssq,
@@ -406,25 +405,21 @@ int swl_gemm_tiny_silu_gate_from_splitk(void *out, const float *slabs_in, int32_
                                         int32_t M, int32_t I, int32_t K, int64_t out_row_stride, int32_t dtype,
                                         swl_stream_t stream);
 
-/* ---- output projection of a decode layer with K split INSIDE the workgroup (csrc/gemm_rows.hip) -------------------------
- * o_proj (reference kernels/linear.py:3-12 at layers/transformer_layer.py:117) and the residual add + element-wise half
- * of the FFN norm that follows it (rmsnorm.py:67-89 at transformer_layer.py:120, in the deferred form of
- * swl_splitk_add_scale) in ONE launch, M <= 32 tokens, packed weight (swl_gemm_pack_weight), K % 1024 == 0, N % 32 == 0:
- *   residual[t, :] += round(x[t, :] . W^T) (stored rounded to the storage dtype, as the reference stores it);
- *   x_scaled = round(residual * norm_w); ssq_out[N / 16][M] = sums of squares of the updated residual rows per 16-column
- *   tile — what swl_gemm_skinny_packed_silu_gate_rs takes as row_ssq with ssq_parts = N / 16 (<= 256).
- * A workgroup owns 16 rows of W for all of K (8 waves x K/8, summed through LDS in K order): no slabs, no consumer launch.
- * swl_gemm_rows_supported: 1 when (M, N, K) is a shape the kernel takes. */
-int swl_gemm_rows_supported(int32_t M, int32_t N, int32_t K);
-/* swl_gemm_rows_add: the same projection with the bare residual add in its epilogue — residual[t, :] += round(x[t, :] . W^T)
- * and nothing else (o_proj at transformer_layer.py:117-120, down_proj at :128 + the next layer's :46). The norm weight and
- * the sums of squares are left to the consumer, which sees every row anyway:
+/* ---- hidden-wide projections of a decode layer with K split INSIDE the workgroup (csrc/gemm_rows.hip) ----------------------
+ * o_proj / down_proj (reference kernels/linear.py:3-12 at layers/transformer_layer.py:117,128) and the residual add that
+ * follows them (rmsnorm.py:54-57 at transformer_layer.py:120 and the next layer's :46) in ONE launch, M <= 32 tokens, packed
+ * weight (swl_gemm_pack_weight), K % 1024 == 0, N % 32 == 0. A workgroup owns 16 rows of W for all of K (8 waves x K/8,
+ * summed through LDS in K order): no slabs, no consumer launch.
+ *   swl_gemm_rows_supported: 1 when (M, N, K) is a shape the kernel takes.
+ *   swl_gemm_rows_add: residual[t, :] += round(x[t, :] . W^T) (stored rounded to the storage dtype, as the reference stores
+ *     it) and nothing else. The norm weight and the sums of squares are left to the consumer, which sees every row anyway:
  *   swl_gemm_skinny_packed_partial_nf ("norm on the fly"): swl_gemm_skinny_packed_partial on x = round(r * norm_w) built
  *     while the raw rows r[M, K] are staged, + ssq_out[k_splits][M] = sum r^2 per K-chunk — the row_ssq of
  *     swl_paged_attn_decode_qkv_rs (ssq_parts = k_splits). Even splits only. The fused qkv projection, :46-56.
  *   swl_gemm_skinny_packed_silu_gate_nf: swl_gemm_skinny_packed_silu_gate_rs with rstd from its own sums (:120-127).
- * Together: a decode layer of <= 16 sequences in 5 launches (qkv, attention, o, up/gate, down) with no slab traffic on the
- * o / down side. */
+ * Together: a decode layer of <= 8 sequences in 5 launches (qkv, attention, o, up/gate, down), 6 up to 32 (down_proj stays
+ * split-K + one consumer there). */
+int swl_gemm_rows_supported(int32_t M, int32_t N, int32_t K);
 int swl_gemm_rows_add(void *residual, const void *x, const void *w_packed, int32_t M, int32_t N, int32_t K,
                       int64_t x_row_stride, int32_t dtype, swl_stream_t stream);
 int swl_gemm_skinny_packed_partial_nf(float *slabs, size_t slabs_bytes, float *ssq_out, const void *x, const void *norm_w,
@@ -433,9 +428,6 @@ int swl_gemm_skinny_packed_partial_nf(float *slabs, size_t slabs_bytes, float *s
 int swl_gemm_skinny_packed_silu_gate_nf(void *out, const void *x, const void *norm_w, float eps,
                                         const void *w_up_gate_packed, int32_t M, int32_t I, int32_t K,
                                         int64_t x_row_stride, int64_t out_row_stride, int32_t dtype, swl_stream_t stream);
-int swl_gemm_rows_add_scale(void *x_scaled, void *residual, float *ssq_out, const void *norm_w, const void *x,
-                            const void *w_packed, int32_t M, int32_t N, int32_t K, int64_t x_row_stride, int32_t dtype,
-                            swl_stream_t stream);
 
 #ifdef __cplusplus
 }

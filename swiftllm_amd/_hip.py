@@ -83,7 +83,6 @@ SIGNATURES = {
     "swl_gemm_tiny_partial_from_attn": [_P, ctypes.c_size_t, _I32, _P, _P, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _P],
     "swl_gemm_tiny_partial_from_splitk": [_P, ctypes.c_size_t, _I32, _P, _P, _I32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
     "swl_gemm_tiny_silu_gate_from_splitk": [_P, _P, _I32, _P, _P, _P, _F32, _P, _I32, _I32, _I32, _I64, _I32, _P],
-    "swl_gemm_rows_add_scale": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I64, _I32, _P],
     "swl_gemm_rows_add": [_P, _P, _P, _I32, _I32, _I32, _I64, _I32, _P],
     "swl_gemm_skinny_packed_partial_nf": [_P, ctypes.c_size_t, _P, _P, _P, _P, _I32, _I32, _I32, _I64, _I32, _I32, _P],
     "swl_gemm_skinny_packed_silu_gate_nf": [_P, _P, _P, _F32, _P, _I32, _I32, _I32, _I64, _I64, _I32, _P],

@@ -1,33 +1,34 @@
-// gemm_rows.hip — the output projection of a decode layer with K split INSIDE the workgroup (gfx950, M <= 32 tokens,
-// packed W), its residual add and the element-wise half of the FFN norm in the epilogue.
+// gemm_rows.hip — the hidden-wide projections of a decode layer with K split INSIDE the workgroup and the residual add in
+// the epilogue (gfx950, M <= 32 tokens, packed W).
 //
-// Replaces, for decode batches of <= 32 tokens in bfloat16, the pair
-//     o_proj (reference swiftllm/worker/kernels/linear.py:3-12 at layers/transformer_layer.py:117)
-//   + fused_add_rmsnorm (kernels/rmsnorm.py:67-89 at transformer_layer.py:120), in its deferred form (rmsnorm.hip:
-//     splitk_add_scale_kernel: residual += round(o); x_scaled = round(residual * w_norm); sums of squares on the side)
+// Replaces, for decode batches of <= 32 (o_proj) / <= 8 (down_proj) tokens in bfloat16, the pair
+//     projection (reference swiftllm/worker/kernels/linear.py:3-12 at layers/transformer_layer.py:117 / :128)
+//   + the residual-add half of fused_add_rmsnorm (kernels/rmsnorm.py:54-57 at transformer_layer.py:120 / the next layer's :46)
 // which r01-r04 ran as a split-K GEMM (8 fp32 slabs, gemm_skinny.hip) followed by a consumer launch that does nothing
-// but wait on memory: 9.6 + 5.0 us per layer in the batch-32 trace (profiles/r04d_kernel_trace_configs2.md) for 33.6 MB
-// of weights = 4.7 us of HBM time.
+// but wait on memory: 9.6 + 5.0 us (o) per layer in the batch-32 trace (profiles/r04d_kernel_trace_configs2.md) for 33.6 MB
+// of weights = 4.7 us of HBM time. The norm weight and the 1/rms are left to the projection that follows, which applies
+// them while it stages the raw residual rows ("norm on the fly": gemm_skinny.hip, NF).
 //
 // Why a second in-workgroup scheme after r02's gemm_wgk (128 workgroups of 32 rows: 11.2 us, retired). What bounds such a
-// kernel on this part is what ONE CU can pull through its L1: ~55 GB/s, hit or miss. A workgroup
-// that owns rows of W for all of K reads all of x[M, K]: bytes per CU = rows * K * e + M * K * e. With 32-row tiles only
-// 128 CUs work and each moves 256 + 256 KiB (9.3 us at 55 GB/s); with SIXTEEN-row tiles all 256 CUs work and each moves
+// kernel on this part is what ONE CU can pull through its L1: ~57 GB/s, L2 hit or HBM miss (DESIGN.md sections 4.6, 4.8). A
+// workgroup that owns rows of W for all of K reads all of x[M, K]: bytes per CU = rows * K * e + M * K * e. With 32-row tiles
+// only 128 CUs work and each moves 256 + 256 KiB (9.3 us); with SIXTEEN-row tiles all 256 CUs work and each moves
 // 128 + 256 KiB (7 us) — and the op is one v_mfma_f32_16x16x32 per 1 KiB of W, so the tile height costs nothing:
 //   * workgroup = 16 rows of W x all of K = 8 waves (2 per SIMD), wave w takes K/8 contiguous columns;
 //   * W comes from the SAME packed copy the other decode kernels stream (swl_gemm_pack_weight: 32-row x 16-k fragments
 //     of 1 KiB): the 16 x 32 A fragment of tile half h is lanes {16h..16h+15} and {32+16h..} of two consecutive
 //     fragments — four 256-byte runs per wave-load, non-temporal; the sibling workgroup reads the other halves;
 //   * x^T is the B operand, loaded straight into fragment layout (lane -> token l%16, 8 k): 64-byte runs of 16 rows,
-//     L2-resident (every workgroup reads the same 256 KiB); rows >= M are clamped to row M-1 (L1 hits, never stored);
+//     L2-resident (every workgroup reads the same rows); rows >= M are clamped to row M-1 (L1 hits, never stored);
 //   * EVERYTHING a wave needs is requested before its first MFMA: K = 4096 is 16 k-steps = 16 + 32 loads of 16 B per
 //     lane (192 VGPRs), the whole workgroup 384 KiB in flight — the kernel is one memory round trip plus a drain at
-//     the CU's own rate; longer K runs the same schedule as a 4-deep ring of 4-step chunks;
+//     the CU's own rate; longer K (down_proj: 14 chunks) refills a 4-deep ring of 4-step chunks behind exact counted waits;
 //   * the 8 waves' 16 x 32 fp32 tiles meet in LDS (20 KiB), are added in wave order (= K order: deterministic), and the
-//     512 threads finish one (token, column) each: splitk_add_scale's arithmetic and rounding points;
-//   * the sum of squares of the new residual row leaves as one partial per (tile, token): ssq_out[N/16][M]; the SiLU-gate
-//     GEMM that applies the deferred 1/rms adds the N/16 partials in a fixed order (swl_gemm_skinny_packed_silu_gate_rs).
-// No slabs, no second launch, no atomics, no cross-workgroup hand-off.
+//     512 threads finish one (token, column) each: residual += round(acc), the consumer launch's rounding points.
+// No slabs, no second launch, no atomics, no cross-workgroup hand-off. (r05 also built an epilogue that wrote
+// round(residual * w_norm) and one sum-of-squares partial per tile, with a SiLU-gate GEMM that added the 256 partials from
+// LDS-DMA'd copies: correct, +2 us on the up/gate kernel, removed — last revision that has it: ca4e9a9, numbers in
+// profiles/r05a_gemm_rows_micro_o_proj_pair.jsonl.)
 #include "swl_common.h"
 
 namespace swl {
@@ -45,25 +46,17 @@ constexpr int kRowsCh = 4;        // k-steps (of 32) per ring chunk
 constexpr int kRowsRing = 4;      // chunks in flight per wave: 16 k-steps = 192 VGPRs at two token blocks
 constexpr int kRowsRedPitch = 20; // floats per token row of a wave's tile image in LDS (80 B: 16-byte stores spread)
 
-enum RowsEpi {
-    kRowsAddScale = 0, // residual += round(acc); xs = round(residual * norm_w); ssq_out[tile][m] = sum of squares
-    kRowsAdd = 1,      // residual += round(acc) only: the consumer applies the norm weight while it stages the rows
-};
-
 struct RowsArgs {
     const void *x;
     const void *wp;
     void *residual;
-    const void *norm_w;
-    void *xs;
-    float *ssq_out; // [N/16][M]
     int M, N, K;
     int64_t x_stride;
 };
 
 // NCH > 0: the chunk count per wave is a compile-time constant <= kRowsRing — every load is issued up front, straight-line
 // code with exact counted waits. NCH == 0: run-time chunk count, the ring refilled behind guards.
-template <typename T, int NCH, int MB, int EPI>
+template <typename T, int NCH, int MB>
 __global__ __launch_bounds__(kRowsWaves * 64, 2) void gemm_rows_kernel(RowsArgs a) {
     __shared__ __attribute__((aligned(16))) float red[kRowsWaves][32 * kRowsRedPitch];
     const int lane = threadIdx.x & 63;
@@ -77,8 +70,6 @@ __global__ __launch_bounds__(kRowsWaves * 64, 2) void gemm_rows_kernel(RowsArgs 
     const bool e_ok = et < M;
     T *res_p = static_cast<T *>(a.residual) + static_cast<int64_t>(e_ok ? et : 0) * N + n0 + en;
     const T rv = *res_p;
-    T nv = T{};
-    if constexpr (EPI == kRowsAddScale) nv = static_cast<const T *>(a.norm_w)[n0 + en];
 
     // ---- the stream ----
     const int r = lane & 15, kq = lane >> 4;
@@ -161,59 +152,28 @@ __global__ __launch_bounds__(kRowsWaves * 64, 2) void gemm_rows_kernel(RowsArgs 
     }
     // splitk_add_scale_kernel's arithmetic (rmsnorm.hip) on this thread's element
     const T xn = add_t<T>(to_t<T>(s), rv); // the projection is rounded, then the sum (rmsnorm.py:54-57)
-    if constexpr (EPI == kRowsAdd) {
-        if (e_ok) *res_p = xn;
-    } else {
-        const float v = to_f(xn);
-        const float ssq = group_allreduce_sum<16>(v * v);
-        const T sv = to_t<T>(v * to_f(nv));
-        if (e_ok) {
-            *res_p = xn;
-            static_cast<T *>(a.xs)[static_cast<int64_t>(et) * N + n0 + en] = sv;
-            if (en == 0) a.ssq_out[static_cast<int64_t>(tile16) * M + et] = ssq;
-        }
-    }
+    if (e_ok) *res_p = xn;
 }
 
 static bool rows_shape_ok(int M, int N, int K) {
     return M > 0 && M <= 32 && N > 0 && N % 32 == 0 && K > 0 && K % (32 * kRowsWaves * kRowsCh) == 0;
 }
 
-template <typename T, int MB, int EPI>
+template <typename T, int MB>
 static int launch_rows(const RowsArgs &a, hipStream_t stream) {
     const dim3 grid(a.N / kRowsTile), block(kRowsWaves * 64);
     const int nch = a.K / (32 * kRowsWaves * kRowsCh);
     // K = 4096 (Llama-3-8B / Llama-2-7B hidden): 4 chunks, all in flight; 14336 (Llama-3-8B FFN): 14; 8192: 8
-    if (nch == 4) hipLaunchKernelGGL((gemm_rows_kernel<T, 4, MB, EPI>), grid, block, 0, stream, a);
-    else if (nch == 14) hipLaunchKernelGGL((gemm_rows_kernel<T, 14, MB, EPI>), grid, block, 0, stream, a);
-    else if (nch == 8) hipLaunchKernelGGL((gemm_rows_kernel<T, 8, MB, EPI>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((gemm_rows_kernel<T, 0, MB, EPI>), grid, block, 0, stream, a);
+    if (nch == 4) hipLaunchKernelGGL((gemm_rows_kernel<T, 4, MB>), grid, block, 0, stream, a);
+    else if (nch == 14) hipLaunchKernelGGL((gemm_rows_kernel<T, 14, MB>), grid, block, 0, stream, a);
+    else if (nch == 8) hipLaunchKernelGGL((gemm_rows_kernel<T, 8, MB>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((gemm_rows_kernel<T, 0, MB>), grid, block, 0, stream, a);
     return check_launch();
 }
 
 } // namespace swl
 
 extern "C" int swl_gemm_rows_supported(int32_t M, int32_t N, int32_t K) { return swl::rows_shape_ok(M, N, K) ? 1 : 0; }
-
-extern "C" int swl_gemm_rows_add_scale(void *x_scaled, void *residual, float *ssq_out, const void *norm_w, const void *x,
-                                       const void *w_packed, int32_t M, int32_t N, int32_t K, int64_t x_row_stride,
-                                       int32_t dtype, swl_stream_t stream) {
-    if (M < 0 || N <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
-    if (M == 0) return SWL_OK;
-    if (!x_scaled || !residual || !ssq_out || !norm_w || !x || !w_packed) return SWL_ERR_BAD_ARG;
-    if (!swl::rows_shape_ok(M, N, K)) return SWL_ERR_UNSUPPORTED;
-    if (x_row_stride < K || (x_row_stride & 7)) return SWL_ERR_BAD_ARG;
-    if (!swl::aligned16(x) || !swl::aligned16(w_packed) || (reinterpret_cast<uintptr_t>(x_scaled) & 1u) ||
-        (reinterpret_cast<uintptr_t>(residual) & 1u) || (reinterpret_cast<uintptr_t>(ssq_out) & 3u))
-        return SWL_ERR_BAD_ARG;
-    swl::RowsArgs a = {};
-    a.x = x; a.wp = w_packed; a.residual = residual; a.norm_w = norm_w; a.xs = x_scaled; a.ssq_out = ssq_out;
-    a.M = M; a.N = N; a.K = K; a.x_stride = x_row_stride;
-    SWL_DISPATCH_DTYPE(dtype, T, {
-        if (M <= 16) return swl::launch_rows<T, 1, swl::kRowsAddScale>(a, static_cast<hipStream_t>(stream));
-        return swl::launch_rows<T, 2, swl::kRowsAddScale>(a, static_cast<hipStream_t>(stream));
-    });
-}
 
 extern "C" int swl_gemm_rows_add(void *residual, const void *x, const void *w_packed, int32_t M, int32_t N, int32_t K,
                                  int64_t x_row_stride, int32_t dtype, swl_stream_t stream) {
@@ -227,7 +187,7 @@ extern "C" int swl_gemm_rows_add(void *residual, const void *x, const void *w_pa
     a.x = x; a.wp = w_packed; a.residual = residual;
     a.M = M; a.N = N; a.K = K; a.x_stride = x_row_stride;
     SWL_DISPATCH_DTYPE(dtype, T, {
-        if (M <= 16) return swl::launch_rows<T, 1, swl::kRowsAdd>(a, static_cast<hipStream_t>(stream));
-        return swl::launch_rows<T, 2, swl::kRowsAdd>(a, static_cast<hipStream_t>(stream));
+        if (M <= 16) return swl::launch_rows<T, 1>(a, static_cast<hipStream_t>(stream));
+        return swl::launch_rows<T, 2>(a, static_cast<hipStream_t>(stream));
     });
 }

@@ -49,7 +49,6 @@ __device__ __forceinline__ float16_t mfma32x32x16(vec8_t<bf16> a, vec8_t<bf16> b
 
 constexpr int kKT = 128;    // k elements per tile (256 bytes per row: two full lines)
 constexpr int kGemmWaves = 4;
-constexpr int kSsqManyParts = 256; // most sums-of-squares partials per token the SiLU-gate GEMM adds itself (MANY)
 
 enum GemmMode {
     kGemmDirect = 0,   // out[M, N] in T
@@ -235,45 +234,26 @@ constexpr int kRing = 3;
 // three — the fused qkv projection of Llama-3-8B is 192 tiles x 4 K-splits = 768 wave-chunks: 192 four-wave workgroups
 // leave a quarter of the 256 CUs idle, 256 three-wave ones fill the chip (r02). Three waves stage the 8 row-groups of the
 // x tile as 3 + 3 + 2: the ninth (dummy) group is a clamped load into four spare LDS rows — no branch in the pipeline.
-// MANY (SiLU-gate mode, packed W): the deferred-RMSNorm sums of squares arrive as up to kSsqManyParts partials per token
-// (gemm_rows.hip writes one per 16-column tile of the residual row: 256 for hidden = 4096) instead of <= 8. They are
-// copied into LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, requested before the first weight tile, so no wait of
-// the weight stream ever includes them) and added in a fixed order after the K loop.
 // NF (packed W, SiLU-gate or partial mode): norm on the fly — x is the raw residual stream r (what gemm_rows.hip leaves
 // behind: no consumer launch computed round(r * norm_w) or the sums of squares). The norm-weight chunk of a K-tile rides
 // with the tile's x loads, the staging pass multiplies and rounds (the bits of splitk_add_scale_kernel) and accumulates
 // sum r^2 per row in fp32 — every workgroup redundantly, it sees all of x anyway.
-template <typename T, int MODE, bool PACKED = false, int RD = kRing, int NWV = kGemmWaves, bool MANY = false, bool NF = false>
+template <typename T, int MODE, bool PACKED = false, int RD = kRing, int NWV = kGemmWaves, bool NF = false>
 // 2 waves per SIMD: the ring holds RD x 8 KiB of W per wave in registers (~220 VGPRs at RD = 3)
 __global__ __launch_bounds__(NWV * 64, 2) void gemm_skinny_ring_kernel(
     void *__restrict__ out_, const T *__restrict__ x, const T *__restrict__ w, int M, int N, int K,
     int kc, int64_t x_stride, int64_t out_stride, GemmExtra fuse) {
     static_assert(NWV == kGemmWaves || (NWV == 3 && PACKED && MODE == kGemmPartial), "3 waves: packed partial only");
-    static_assert(!MANY || (PACKED && MODE == kGemmSiluGate && NWV == kGemmWaves), "many ssq partials: packed SiLU-gate only");
-    static_assert(!NF || (PACKED && !MANY && MODE != kGemmDirect), "norm on the fly: packed SiLU-gate / partial only");
+    static_assert(!NF || (PACKED && MODE != kGemmDirect), "norm on the fly: packed SiLU-gate / partial only");
     constexpr int D = RD;
     constexpr int XL = (8 + NWV - 1) / NWV; // x row-groups (4 rows each) a wave stages per tile
     constexpr int XROWS = 4 * XL * NWV;      // 32, or 36 with the dummy group of the 3-wave variant
     // [0..1] the double-buffered x tile of the workgroup, [2 + wave] the wave-private W tile (row-major W only)
     __shared__ __attribute__((aligned(16))) T lds[2 + (PACKED ? 0 : kGemmWaves)][XROWS * kKT];
-    __shared__ __attribute__((aligned(16))) float ssq_lds[MANY ? kSsqManyParts * 32 : 4];
-    __shared__ float ssq_red[MANY ? 8 : 1][32];
     __shared__ float ssq_row[NF ? XROWS : 1];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if constexpr (MANY) {
-        // flat copy of ssq_in[ssq_parts][M] (a multiple of 4 floats, 16-byte aligned): 1 KiB per wave-instruction
-        const int total = fuse.ssq_parts * M;
-#pragma unroll
-        for (int i = 0; i < kSsqManyParts * 32 / (kGemmWaves * 256); ++i) {
-            const int off = (i * kGemmWaves + wave) * 256;
-            if (off + lane * 4 < total)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(fuse.ssq_in + off + lane * 4),
-                    (__attribute__((address_space(3))) void *)(ssq_lds + off), 16, 0, 0);
-        }
-    }
     const bool is_gate = MODE == kGemmSiluGate && wave >= 2;
     const int col0 = MODE == kGemmSiluGate ? (blockIdx.x * 2 + (wave & 1)) * 32
                                            : (blockIdx.x * NWV + wave) * 32;
@@ -316,7 +296,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_skinny_ring_kernel(
     // BEFORE the weight stream (oldest loads: no wait of the pipeline ever includes them) and summed after the K loop
     float ssv[8];
     const bool row_scaled = PACKED && MODE == kGemmSiluGate && (NF || fuse.ssq_in != nullptr);
-    if (row_scaled && !MANY && !NF) {
+    if (row_scaled && !NF) {
         const int m = min(lane & 31, M - 1);
 #pragma unroll
         for (int p2 = 0; p2 < 8; ++p2) ssv[p2] = p2 < fuse.ssq_parts ? fuse.ssq_in[p2 * M + m] : 0.f;
@@ -424,20 +404,6 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_skinny_ring_kernel(
             if (blockIdx.x == 0 && wave == 0 && lane < M) fuse.ssq_out[ksplit * M + lane] = ssq_row[lane];
         }
         float rs = 1.0f;
-        if constexpr (MANY) {
-            // (every load of this wave — its LDS-DMA pieces included — was waited for by the K loop's last tile; the
-            // barrier above covers the other waves' pieces.) group g = 2 * wave + lane / 32 adds partials g, g + 8, ...
-            // of token lane % 32 in order; the eight group sums are added as the <= 8-partial form adds its partials.
-            __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) (explicit: the DMA's LDS side is invisible to the K loop's waits)
-            __syncthreads();
-            const int m = min(lane & 31, M - 1), g = 2 * wave + (lane >> 5);
-            float t = 0.f;
-            for (int p2 = g; p2 < fuse.ssq_parts; p2 += 8) t += ssq_lds[p2 * M + m];
-            ssq_red[g][lane & 31] = t;
-            __syncthreads();
-#pragma unroll
-            for (int p2 = 0; p2 < 8; ++p2) ssv[p2] = ssq_red[p2][lane & 31];
-        }
         if constexpr (NF && MODE == kGemmSiluGate) {
             rs = 1.0f / sqrtf(ssq_row[min(lane & 31, M - 1)] / static_cast<float>(K) + fuse.eps);
         } else if (row_scaled) {
@@ -813,7 +779,7 @@ extern "C" int swl_gemm_skinny_packed_silu_gate_rs(void *out, const void *x, con
     if (M < 0 || I <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
     if (M == 0) return SWL_OK;
     if (!out || !x || !w_up_gate_packed || !row_ssq || ssq_parts <= 0) return SWL_ERR_BAD_ARG;
-    if (M > 32 || (I & 31) || (K & (swl::kKT - 1)) || ssq_parts > swl::kSsqManyParts) return SWL_ERR_UNSUPPORTED;
+    if (M > 32 || (I & 31) || (K & (swl::kKT - 1)) || ssq_parts > 8) return SWL_ERR_UNSUPPORTED;
     if (x_row_stride < K || out_row_stride < I || (x_row_stride & 7) || (out_row_stride & 3)) return SWL_ERR_BAD_ARG;
     if (!swl::aligned16(x) || !swl::aligned16(w_up_gate_packed) || (reinterpret_cast<uintptr_t>(out) & 7u))
         return SWL_ERR_BAD_ARG;
@@ -822,22 +788,6 @@ extern "C" int swl_gemm_skinny_packed_silu_gate_rs(void *out, const void *x, con
     f.ssq_parts = ssq_parts;
     f.eps = eps;
     const dim3 grid((I / 32 + 1) / 2, 1);
-    if (ssq_parts > 8) { // one partial per 16-column tile of the residual row (swl_gemm_rows_add_scale): LDS-DMA + in-kernel sum
-        if (!swl::aligned16(row_ssq) || ((static_cast<int64_t>(ssq_parts) * M) & 3)) return SWL_ERR_BAD_ARG;
-        SWL_DISPATCH_DTYPE(dtype, T, {
-            if (swl::use_ring(K))
-                hipLaunchKernelGGL((swl::gemm_skinny_ring_kernel<T, swl::kGemmSiluGate, true, 3, swl::kGemmWaves, true>), grid,
-                                   dim3(swl::kGemmWaves * 64), 0, static_cast<hipStream_t>(stream), out,
-                                   static_cast<const T *>(x), static_cast<const T *>(w_up_gate_packed), M, I, K, K,
-                                   x_row_stride, out_row_stride, f);
-            else
-                hipLaunchKernelGGL((swl::gemm_skinny_ring_kernel<T, swl::kGemmSiluGate, true, 2, swl::kGemmWaves, true>), grid,
-                                   dim3(swl::kGemmWaves * 64), 0, static_cast<hipStream_t>(stream), out,
-                                   static_cast<const T *>(x), static_cast<const T *>(w_up_gate_packed), M, I, K, K,
-                                   x_row_stride, out_row_stride, f);
-        });
-        return swl::check_launch();
-    }
     SWL_DISPATCH_DTYPE(dtype, T, {
         swl::launch_packed<T, swl::kGemmSiluGate>(grid, static_cast<hipStream_t>(stream), out, static_cast<const T *>(x),
                                                   static_cast<const T *>(w_up_gate_packed), M, I, K, K, x_row_stride,
@@ -873,7 +823,7 @@ extern "C" int swl_gemm_skinny_packed_partial_nf(float *slabs, size_t slabs_byte
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t n64 = N;
 #define SWL_NF_PARTIAL(RD_, NWV_)                                                                                        \
-    hipLaunchKernelGGL((swl::gemm_skinny_ring_kernel<T, swl::kGemmPartial, true, RD_, NWV_, false, true>), grid,          \
+    hipLaunchKernelGGL((swl::gemm_skinny_ring_kernel<T, swl::kGemmPartial, true, RD_, NWV_, true>), grid,          \
                        dim3(NWV_ * 64), 0, s, static_cast<void *>(slabs), static_cast<const T *>(x),                     \
                        static_cast<const T *>(w_packed), M, N, K, kc, x_row_stride, n64, f)
     SWL_DISPATCH_DTYPE(dtype, T, {
@@ -913,11 +863,11 @@ extern "C" int swl_gemm_skinny_packed_silu_gate_nf(void *out, const void *x, con
     hipStream_t s = static_cast<hipStream_t>(stream);
     SWL_DISPATCH_DTYPE(dtype, T, {
         if (swl::use_ring(K))
-            hipLaunchKernelGGL((swl::gemm_skinny_ring_kernel<T, swl::kGemmSiluGate, true, 3, swl::kGemmWaves, false, true>),
+            hipLaunchKernelGGL((swl::gemm_skinny_ring_kernel<T, swl::kGemmSiluGate, true, 3, swl::kGemmWaves, true>),
                                grid, dim3(swl::kGemmWaves * 64), 0, s, out, static_cast<const T *>(x),
                                static_cast<const T *>(w_up_gate_packed), M, I, K, K, x_row_stride, out_row_stride, f);
         else
-            hipLaunchKernelGGL((swl::gemm_skinny_ring_kernel<T, swl::kGemmSiluGate, true, 2, swl::kGemmWaves, false, true>),
+            hipLaunchKernelGGL((swl::gemm_skinny_ring_kernel<T, swl::kGemmSiluGate, true, 2, swl::kGemmWaves, true>),
                                grid, dim3(swl::kGemmWaves * 64), 0, s, out, static_cast<const T *>(x),
                                static_cast<const T *>(w_up_gate_packed), M, I, K, K, x_row_stride, out_row_stride, f);
     });

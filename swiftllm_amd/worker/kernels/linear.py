@@ -317,37 +317,7 @@ def linear_silu_gate(a: torch.Tensor, w_up_gate: torch.Tensor, row_scale=None):
     return out
 
 
-# ---- o_proj with K split inside the workgroup + residual add + deferred-norm half in its epilogue (csrc/gemm_rows.hip) --
-_ROWS_MAX_PARTS = 256       # kSsqManyParts: sums-of-squares partials the SiLU-gate GEMM adds itself (one per 16 columns)
-
-
-def rows_add_scale_ok(a: torch.Tensor, w: torch.Tensor, residual: torch.Tensor) -> bool:
-    """Can `linear_rows_add_scale` run o_proj + residual add + round(residual * norm_w) in one launch? bfloat16 (the
-    deferred norm's policy, kernels/rmsnorm.py: deferred_norm_ok), <= 32 tokens, packed weight, hidden <= 4096."""
-    if _packed_of(w) is None or not _skinny_ok(a, w) or a.dtype != torch.bfloat16:
-        return False
-    m, k = a.shape
-    n = w.shape[0]
-    return (residual.is_contiguous() and residual.shape == (m, n) and n // 16 <= _ROWS_MAX_PARTS
-            and bool(_hip.load().swl_gemm_rows_supported(m, n, k)))
-
-
-def linear_rows_add_scale(a: torch.Tensor, w: torch.Tensor, residual_io: torch.Tensor, norm_w: torch.Tensor, eps: float):
-    """residual_io += round(a @ w^T); returns RowScalePending(round(residual_io * norm_w), ssq[N/16, M]) — what
-    linear_splitk + add_scale_from_splitk return, in one launch and without slabs (another fp32 summation order of the
-    same products: K/8 runs per wave added in K order)."""
-    from .rmsnorm import RowScalePending
-    assert rows_add_scale_ok(a, w, residual_io) and norm_w.dtype == a.dtype and norm_w.is_contiguous()
-    m, k = a.shape
-    n = w.shape[0]
-    xs = torch.empty((m, n), dtype=a.dtype, device=a.device)
-    parts = n // 16
-    ssq = torch.empty((parts, m), dtype=torch.float32, device=a.device)
-    _hip.call("swl_gemm_rows_add_scale", _hip.ptr(xs), _hip.ptr(residual_io), _hip.ptr(ssq), _hip.ptr(norm_w), _hip.ptr(a),
-              _hip.ptr(_packed_of(w)), m, n, k, _row_stride(a), _hip.dtype_code(a.dtype), _hip.stream())
-    return RowScalePending(xs, ssq, parts, eps)
-
-
+# ---- o_proj / down_proj with K split inside the workgroup and the residual add in the epilogue (csrc/gemm_rows.hip) ----
 class RawResidual:
     """What a layer hands to the next one when its down projection already added itself into the residual buffer
     (linear_rows_add): there is no activation tensor and no slabs — the residual rows ARE the layer output, and the next

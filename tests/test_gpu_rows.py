@@ -75,36 +75,6 @@ def test_rows_add_carries_the_bits_of_splitk_plus_consumer(M, N, K):
     assert ((r_old.float() - r_new.float()).abs() <= 2.0 ** -7 * r_old.float().abs() + 1e-6).all()
 
 
-@pytest.mark.parametrize("M", [1, 5, 16, 32])
-def test_rows_add_scale_and_many_partial_silu_gate(M):
-    """The add+scale epilogue form: x_scaled == round(residual * w) bit for bit, the 256 per-tile partials add up to the
-    row's sum of squares, and the SiLU-gate GEMM that adds them itself (LDS-DMA, fixed order) agrees with the same GEMM fed
-    <= 8 partials of the same rows to fp32 rounding of the 1/rms."""
-    from swiftllm_amd.worker.kernels.linear import pack_weight, linear_rows_add_scale, linear_silu_gate, rows_add_scale_ok
-    from swiftllm_amd.worker.kernels.rmsnorm import RowScalePending
-    dtype = torch.bfloat16
-    h, inter = 4096, 14336
-    g = gen(M + 11)
-    a = torch.randn(M, h, generator=g).to(dtype).cuda()
-    wo = (torch.randn(h, h, generator=g) * 0.02).to(dtype).cuda()
-    wug = (torch.randn(2 * inter, h, generator=g) * 0.02).to(dtype).cuda()
-    pack_weight(wo)
-    pack_weight(wug)
-    res = (2 * torch.randn(M, h, generator=g)).to(dtype).cuda()
-    nw = (1 + 0.1 * torch.randn(h, generator=g)).to(dtype).cuda()
-    assert rows_add_scale_ok(a, wo, res)
-    pend = linear_rows_add_scale(a, wo, res, nw, 1e-5)
-    assert pend.ssq.shape == (h // 16, M)
-    assert torch.equal(pend.x, (res.float() * nw.float()).to(dtype))
-    want = res.double().pow(2).sum(1)
-    assert torch.allclose(pend.ssq.double().sum(0), want, rtol=1e-5)
-    ssq8 = res.float().pow(2).view(M, h // 1024, 1024).sum(2).t().contiguous()
-    a8 = linear_silu_gate(pend.x, wug, row_scale=RowScalePending(pend.x, ssq8, h // 1024, 1e-5))
-    a256 = linear_silu_gate(pend.x, wug, row_scale=pend)
-    scale = a8.float().abs().amax(dim=1, keepdim=True).clamp(min=1e-3)
-    assert ((a8.float() - a256.float()).abs() / scale).max().item() <= 2.0 ** -7
-
-
 @pytest.mark.parametrize("M", [1, 3, 8, 16, 32])
 def test_norm_on_the_fly_projections(M):
     """linear_splitk_nf / linear_silu_gate_nf on the raw residual rows against add-scale-then-project: the staged

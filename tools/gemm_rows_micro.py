@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
-"""gemm_rows_micro.py — swl_gemm_rows_add_scale (csrc/gemm_rows.hip: o_proj with K split inside the workgroup, residual add
-and the deferred norm's element-wise half in its epilogue) against the pair it replaces (swl_gemm_skinny_packed_partial +
-swl_splitk_add_scale), alone and in the chain o_proj -> [consumer] -> up/gate SiLU GEMM -> down, at Llama-3-8B widths (GPU).
-Checks both forms against an fp64 product first; times launches that cycle through distinct weight copies, eagerly and as
-one captured hipGraph per chain (what the decode step replays). One JSON line per batch size."""
+"""gemm_rows_micro.py — the row-owned decode projections (csrc/gemm_rows.hip: K split inside the workgroup, residual add in the
+epilogue) and norm on the fly (csrc/gemm_skinny.hip NF) at Llama-3-8B widths (GPU):
+    --layer       the projection side of one decode layer three ways (split-K + consumers | r02 tiny path | rows + NF), each
+                  checked against the others first, timed as captured hipGraphs cycling through distinct weight copies;
+    --pmc o|down  only swl_gemm_rows_add in a loop (for rocprofv3 --pmc passes, tools/gpu_pmc_rows.sh).
+One JSON line per batch size."""
 import argparse, json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from swiftllm_amd.worker.kernels.linear import (pack_weight, linear_splitk, linear_rows_add_scale, rows_add_scale_ok,
-                                                linear_silu_gate, SplitKPartials, linear_rows_add, linear_splitk_nf,
+from swiftllm_amd.worker.kernels.linear import (pack_weight, linear_splitk,                                                 linear_silu_gate, SplitKPartials, linear_rows_add, linear_splitk_nf,
                                                 linear_silu_gate_nf, linear_splitk_from_splitk, linear_silu_gate_from_splitk,
                                                 alt_residual_like, tiny_from_splitk_ok)
 from swiftllm_amd.worker.kernels.rmsnorm import add_scale_from_splitk
@@ -168,80 +168,8 @@ def main():
         return pmc_mode(a)
     if a.layer:
         return layer_mode(a)
-    dt = torch.bfloat16
-    H, I = a.hidden, a.inter
-    g = torch.Generator(device="cuda").manual_seed(0)
-    wo = [(torch.randn(H, H, device="cuda", generator=g) * 0.02).to(dt) for _ in range(a.copies)]
-    for w in wo:
-        pack_weight(w)
-    wug = [(torch.randn(2 * I, H, device="cuda", generator=g) * 0.02).to(dt) for _ in range(a.copies)]
-    wdn = [(torch.randn(H, I, device="cuda", generator=g) * 0.02).to(dt) for _ in range(a.copies)]
-    for w in wug + wdn:
-        pack_weight(w)
-    norm_w = (1.0 + 0.1 * torch.randn(H, device="cuda", generator=g)).to(dt)
-    eps = 1e-5
-    for M in [int(v) for v in a.m.split(",")]:
-        x = torch.randn(M, H, device="cuda", generator=g).to(dt)
-        res0 = torch.randn(M, H, device="cuda", generator=g).to(dt)
-        row = dict(M=M, N=H, K=H, MB=round(H * H * 2 / 1e6, 1), supported=bool(rows_add_scale_ok(x, wo[0], res0)))
-        # ---- correctness: both forms against fp64 --------------------------------------------------------------------
-        ref_o = (x.double() @ wo[0].double().t())
-        ref_res = (ref_o.to(dt).double() + res0.double())            # (the rounding points of the op, on the exact product)
-        r_old = res0.clone()
-        part = linear_splitk(x, wo[0])
-        assert isinstance(part, SplitKPartials)
-        row["ks_old"] = part.k_splits
-        p_old = add_scale_from_splitk(part, r_old, norm_w, eps)
-        r_new = res0.clone()
-        p_new = linear_rows_add_scale(x, wo[0], r_new, norm_w, eps)
-        torch.cuda.synchronize()
-        scale = float(ref_res.abs().max())
-        row["res_err_old"] = float((r_old.double() - ref_res).abs().max()) / scale
-        row["res_err_new"] = float((r_new.double() - ref_res).abs().max()) / scale
-        row["res_new_vs_old_diff_frac"] = float((r_new != r_old).float().mean())
-        row["xs_new_vs_own_residual_bit_equal"] = bool(torch.equal(p_new.x, (r_new.float() * norm_w.float()).to(dt)))
-        ssq_ref = (r_new.double() ** 2).sum(1)
-        row["ssq_rel_err_new"] = float(((p_new.ssq.double().sum(0) - ssq_ref).abs() / ssq_ref).max())
-        # the consumer: SiLU-gate GEMM with 8 / 256 partials of the SAME residual must agree to fp32 rounding of rstd
-        ssq8 = (r_new.float() ** 2).view(M, H // 1024, 1024).sum(2).t().contiguous()
-        from swiftllm_amd.worker.kernels.rmsnorm import RowScalePending
-        a8 = linear_silu_gate(p_new.x, wug[0], row_scale=RowScalePending(p_new.x, ssq8, H // 1024, eps))
-        a256 = linear_silu_gate(p_new.x, wug[0], row_scale=p_new)
-        torch.cuda.synchronize()
-        row["silu_many_vs_8_diff_frac"] = float((a8 != a256).float().mean())
-        row["silu_many_vs_8_maxrel"] = float(((a8.float() - a256.float()).abs().max() / a8.float().abs().max()))
-        # ---- timing: the op alone ------------------------------------------------------------------------------------
-        rbuf = res0.clone()
-
-        def old_pair(i):
-            return add_scale_from_splitk(linear_splitk(x, wo[i % a.copies]), rbuf, norm_w, eps)
-
-        def new_one(i):
-            return linear_rows_add_scale(x, wo[i % a.copies], rbuf, norm_w, eps)
-
-        row["old_gemm_us"] = round(time_us(lambda i: linear_splitk(x, wo[i % a.copies]), a.iters), 2)
-        row["old_pair_us"] = round(time_us(old_pair, a.iters), 2)
-        row["new_us"] = round(time_us(new_one, a.iters), 2)
-        row["old_pair_graph_us"] = round(graph_us(old_pair, a.copies, a.iters), 2)
-        row["new_graph_us"] = round(graph_us(new_one, a.copies, a.iters), 2)
-        row["silu8_us"] = round(time_us(lambda i: linear_silu_gate(p_new.x, wug[i % a.copies],
-                                                                   row_scale=RowScalePending(p_new.x, ssq8, H // 1024, eps)), a.iters), 2)
-        row["silu256_us"] = round(time_us(lambda i: linear_silu_gate(p_new.x, wug[i % a.copies], row_scale=p_new), a.iters), 2)
-        # ---- timing: the chain o_proj -> up/gate -> down as the layer runs it, captured ----------------------------------
-        if not a.no_chain:
-            def chain_old(i):
-                pend = add_scale_from_splitk(linear_splitk(x, wo[i % a.copies]), rbuf, norm_w, eps)
-                act = linear_silu_gate(pend.x, wug[i % a.copies], row_scale=pend)
-                return linear_splitk(act, wdn[i % a.copies])
-
-            def chain_new(i):
-                pend = linear_rows_add_scale(x, wo[i % a.copies], rbuf, norm_w, eps)
-                act = linear_silu_gate(pend.x, wug[i % a.copies], row_scale=pend)
-                return linear_splitk(act, wdn[i % a.copies])
-
-            row["chain_old_graph_us"] = round(graph_us(chain_old, a.copies, a.iters), 2)
-            row["chain_new_graph_us"] = round(graph_us(chain_new, a.copies, a.iters), 2)
-        print(json.dumps(row), flush=True)
+    raise SystemExit("pick a mode: --layer (projection side of a decode layer, three ways) or --pmc o|down; the r05a o_proj-pair "
+                     "mode (swl_gemm_rows_add_scale, removed) is in revision ca4e9a9")
 
 
 if __name__ == "__main__":

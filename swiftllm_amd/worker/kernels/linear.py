@@ -10,8 +10,10 @@ projection is pure HBM streaming of the weight matrix, 77 % of all bytes a decod
 
 Weights that carry a packed twin (`pack_weight`: a copy in MFMA-fragment order made at load time,
 EngineConfig.pack_decode_weights) are streamed from that copy — same bits, 6-9 % faster (long sequential DRAM
-bursts, no LDS transpose) — and additionally serve decode batches of 33..128 tokens (`swl_gemm_packed_mid`: 2 or 4
-blocks of 32 tokens share every weight fragment; used up to 64 tokens, and above that where K >= 2N).
+bursts, no LDS transpose) — and additionally serve decode batches of 33..64 tokens (`swl_gemm_packed_mid`: 2 blocks of
+32 tokens share every weight fragment) and, where measured faster than the library, 65..256 (`swl_gemm_packed_wide`).
+For <= 32 tokens in bfloat16, o_proj / down_proj can finish their rows inside the workgroup (`linear_rows_add`) and the
+projection after them normalises the raw residual rows on the fly (`linear_splitk_nf`, `linear_silu_gate_nf`).
 
 `linear_splitk` is the same product stopped one step earlier: when the kernel splits K across
 workgroups it returns the fp32 partial slabs (`SplitKPartials`) instead of launching the reduce, and a

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/gpu_trace.sh — rocprofv3 --kernel-trace --stats of short bench runs; prints / saves the per-kernel tables.
 #   TRACES="c2 c1 c3" (default): BASELINE configs[2] (batch 32, prompt pass + decode), configs[1] (batch 1), configs[3]
-#   (Llama-2-7B dims, 4 x 16k, KV pre-filled); b128 / b256: decode-only at batch 128 / 256 (KV pre-filled). Output: gpurun_out/trace_<name>.md (+ the bench line in trace_<name>.log)
+#   (Llama-2-7B dims, 4 x 16k, KV pre-filled); b8: decode-only at batch 8 (the 5-launch layer of r05); b128 / b256: decode-only at batch 128 / 256 (KV pre-filled). Output: gpurun_out/trace_<name>.md (+ the bench line in trace_<name>.log)
 mkdir -p gpurun_out
 REPO=$(pwd)
 export TMPDIR=/tmp
@@ -10,6 +10,7 @@ for t in ${TRACES:-c2 c1 c3}; do
   case $t in
     c2) ARGS="--steps 24 --warmup 4" ;;
     c1) ARGS="--batch 1 --steps 24 --warmup 4" ;;
+    b8) ARGS="--batch 8 --skip-prefill --steps 24 --warmup 4" ;;
     c3) ARGS="--model llama2-7b --batch 4 --prompt-len 16384 --gen-len 64 --skip-prefill --steps 24 --warmup 4" ;;
     b128) ARGS="--batch 128 --skip-prefill --steps 16 --warmup 4 --kv-placement bottom" ;;
     b256) ARGS="--batch 256 --skip-prefill --steps 16 --warmup 4 --kv-placement bottom" ;;

@@ -83,6 +83,8 @@ def parse_args():
     ap.add_argument("--no-packed-weights", dest="packed_weights", action="store_false")
     ap.add_argument("--no-rows-decode", dest="rows_decode", action="store_false",
                     help="A/B: split-K + consumer launches for o_proj / down_proj instead of the row-owned kernels (r05)")
+    ap.add_argument("--no-decode-engine", dest="decode_engine", action="store_false",
+                    help="one-sequence steps on the multi-launch path instead of the persistent decode engine (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[1] / configs[3] / eager side runs")
     ap.add_argument("--skip-prefill", action="store_true", help="fill the KV pool directly instead of running the prompt")
@@ -141,7 +143,8 @@ def build_model(args, cfg, min_blocks, batch, max_len, hip_graph):
                       max_blocks_per_seq=max(FILLER_BLOCKS_PER_SEQ, max_len // 16 + 8),
                       max_batch_size=batch, max_tokens_in_batch=batch * min(max_len, 8192),
                       dtype=args.dtype, fuse_qkv=args.fuse_qkv, use_hip_graph=hip_graph,
-                      use_skinny_gemm=args.skinny_gemm, tuning=dict(fuse_splitk_consumers=args.splitk_fusion, rows_decode=getattr(args, "rows_decode", True)),
+                      use_skinny_gemm=args.skinny_gemm, tuning=dict(fuse_splitk_consumers=args.splitk_fusion, rows_decode=getattr(args, "rows_decode", True),
+                                  decode_engine=getattr(args, "decode_engine", True)),
                       pack_decode_weights=getattr(args, "packed_weights", True))
     model = LlamaModel(ec)
     model.load_weights()

@@ -429,6 +429,45 @@ int swl_gemm_skinny_packed_silu_gate_nf(void *out, const void *x, const void *no
                                         const void *w_up_gate_packed, int32_t M, int32_t I, int32_t K,
                                         int64_t x_row_stride, int64_t out_row_stride, int32_t dtype, swl_stream_t stream);
 
+/* ---- the transformer stack of a one-sequence decode step as ONE persistent launch (csrc/decode_engine.hip) ----------------
+ * reference: the layer loop of LlamaModel._forward (swiftllm/worker/model.py:228-249) over
+ * LlamaTransformerLayer.forward (swiftllm/worker/layers/transformer_layer.py:31-130) for ONE decoding sequence: embedding row
+ * (pre_layer.py:15-20), and per layer fused add + RMSNorm (rmsnorm.py:39-89), q/k/v projections (linear.py:3-12), rotary
+ * (rotary_emb.py:7-58), KV store of the new token (kvcache_mgmt.py:50-79), paged attention phase 1 + 2
+ * (paged_attn.py:9-149), o projection, fused add + RMSNorm, up/gate projection, SiLU-gate (silu_and_mul.py:5-34), down
+ * projection — with the reference's rounding points in BOTH dtypes. 256 workgroups (one per CU): a loader wave streams a
+ * per-CU weight stream by LDS-DMA through a 7 x 16 KiB ring, three consumer waves do the arithmetic; operator boundaries
+ * are all-to-all hand-offs of 8-byte {tag, payload} granules inside the launch; every wait is bounded.
+ *   swl_decode_engine_supported: 1 when the model shape and the device (num_cus == 256, head_dim == 128, H*D == hidden,
+ *     H/KVH in {1, 2, 4}, hidden and ffn_inter_dim multiples of 2048 ...) are what the kernel is laid out for.
+ *   swl_decode_engine_slots_per_layer: 16 KiB slots one CU streams per layer (0: unsupported). The weight stream is
+ *     [num_layers][256][slots][8192 elements]: per CU and layer qkv | o | up,gate | down; an operator's slots are ordered
+ *     (row group of 8, k-chunk of 1024); inside a slot piece p (1 KiB), lane l holds W[row 8g + l/8][1024j + 64p + 8(l%8) ..+8]
+ *     (swiftllm_amd/worker/decode_engine.py: pack_engine_layer). CU c owns rows [c*N/256, (c+1)*N/256) of every projection
+ *     (up rows and the matching gate rows for the FFN).
+ *   swl_decode_engine_workspace_bytes / swl_decode_engine_reset: the hand-off workspace (state words + granule regions);
+ *     reset zeroes it and starts the epoch counter (synchronises the stream). Call once after allocation and after any
+ *     step that reported an error.
+ *   swl_decode_engine_step: resid_out[hidden] = the residual stream after the last layer for the sequence described by
+ *     input_ids[0] / seq_ids[0] / seq_lens[0] (length INCLUDING the token being decoded, model.py:296); writes the new
+ *     token's K/V into the pools. err_out (may be NULL) receives 0, or the code of a timed-out wait (the workspace then stays
+ *     poisoned until reset: later steps return at once with the same code). debug_stamps (may be NULL): [num_layers][8]
+ *     100 MHz timestamps of CU 0's phases. Must not run concurrently with another kernel on the device (one workgroup per
+ *     CU, all 256 resident). */
+int swl_decode_engine_supported(int32_t hidden, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
+                                int32_t ffn_inter_dim, int32_t num_cus);
+int swl_decode_engine_slots_per_layer(int32_t hidden, int32_t num_q_heads, int32_t num_kv_heads, int32_t ffn_inter_dim);
+size_t swl_decode_engine_workspace_bytes(int32_t hidden, int32_t num_q_heads, int32_t num_kv_heads,
+                                         int32_t ffn_inter_dim);
+int swl_decode_engine_reset(void *workspace, size_t workspace_bytes, swl_stream_t stream);
+int swl_decode_engine_step(void *resid_out, const void *w_stream, const void *norms, const void *wte, void *k_cache,
+                           void *v_cache, const int32_t *block_table, const int32_t *input_ids, const int32_t *seq_ids,
+                           const int32_t *seq_lens, const void *cos_table, const void *sin_table, void *workspace,
+                           size_t workspace_bytes, int64_t *err_out, uint64_t *debug_stamps, int32_t num_layers,
+                           int32_t hidden, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
+                           int32_t ffn_inter_dim, int32_t max_blocks_per_seq, float eps, float softmax_scale,
+                           int32_t dtype, swl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,9 @@ SIGNATURES = {
     "swl_gemm_rows_add": [_P, _P, _P, _I32, _I32, _I32, _I64, _I32, _P],
     "swl_gemm_skinny_packed_partial_nf": [_P, ctypes.c_size_t, _P, _P, _P, _P, _I32, _I32, _I32, _I64, _I32, _I32, _P],
     "swl_gemm_skinny_packed_silu_gate_nf": [_P, _P, _P, _F32, _P, _I32, _I32, _I32, _I64, _I64, _I32, _P],
+    "swl_decode_engine_reset": [_P, ctypes.c_size_t, _P],
+    "swl_decode_engine_step": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P, _P, _I32, _I32,
+                               _I32, _I32, _I32, _I32, _I32, _F32, _F32, _I32, _P],
 }
 # Entry points that do not follow the "int rc = f(...)" convention.
 _SPECIAL = {
@@ -101,6 +104,9 @@ _SPECIAL = {
     "swl_gemm_packed_wide_choose_splits": ([_I32, _I32, _I32], _I32),
     "swl_gemm_tiny_max_tokens": ([], _I32),
     "swl_gemm_rows_supported": ([_I32, _I32, _I32], _I32),
+    "swl_decode_engine_supported": ([_I32, _I32, _I32, _I32, _I32, _I32], _I32),
+    "swl_decode_engine_slots_per_layer": ([_I32, _I32, _I32, _I32], _I32),
+    "swl_decode_engine_workspace_bytes": ([_I32, _I32, _I32, _I32], ctypes.c_size_t),
 }
 
 _lock = threading.Lock()

@@ -28,8 +28,9 @@ SOURCES = [
     "gemm_wide.hip",
     "gemm_rows.hip",
     "argmax.hip",
+    "decode_engine.hip",
 ]
-HEADERS = ["swl_common.h", os.path.join(ROOT, "include", "swiftllm_hip.h")]
+HEADERS = ["swl_common.h", "attend_block.h", os.path.join(ROOT, "include", "swiftllm_hip.h")]
 LIB = os.path.join(HERE, "libswiftllm_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")
 ARCH = "gfx950"

@@ -71,6 +71,11 @@ class EngineConfig:
         # no consumer launch), and the projection that follows applies the norm weight and the 1/rms itself while it stages
         # the raw residual rows ("norm on the fly", gemm_skinny.hip NF): 6 launches per layer at batch 32, 5 up to batch 8
         rows_decode=True,
+        # ONE decoding sequence: the whole transformer stack of the step is one persistent launch (csrc/decode_engine.hip: a
+        # loader wave per CU streams that CU's rows of every projection by LDS-DMA, three consumer waves compute, operator
+        # boundaries are in-launch granule hand-offs) — the reference's rounding points in BOTH dtypes. Costs a third copy of
+        # the layer weights (13.9 GB for Llama-3-8B). Shapes the kernel is not laid out for run the multi-launch path.
+        decode_engine=True,
         pin_swap_memory=True,           # host swap pool in pinned memory (falls back to pageable when the host refuses)
     )
 

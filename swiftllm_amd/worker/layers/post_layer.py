@@ -29,11 +29,11 @@ class LlamaPostLayer:
         rmsnorm_inplace(last_input, self.weights.final_norm, self.model_config.rms_norm_eps)
         return self.forward_normed(last_input)
 
-    def forward_normed(self, last_input: torch.Tensor) -> torch.Tensor:
+    def forward_normed(self, last_input: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         """lm_head + greedy sampling on rows that already went through the final norm (a pure-decode batch whose
         last add + norm ran fused on the split-K partials of the last down projection: every row is a last token)."""
         logits = linear(last_input, self.weights.lm_head, self.skinny)   # [batch, vocab]
         self.last_logits = logits
         if self.logits_tap is not None:
             self.logits_tap.append(logits)
-        return argmax_rows(logits)
+        return argmax_rows(logits, out)

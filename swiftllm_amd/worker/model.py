@@ -33,6 +33,7 @@ from swiftllm_amd.utils import GB
 
 from .batch_plan import BatchPlan, plan_batch
 from .block_manager import BlockManager
+from . import decode_engine as _decode_engine
 from .infer_state import LlamaInferState
 from .kernels.block_swapping import swap_blocks
 from .kernels.linear import RawResidual
@@ -56,7 +57,7 @@ def _require_hip_device():
 
 class _DecodeGraph:
     """A captured pure-decode forward for one batch size."""
-    __slots__ = ("graph", "out_tokens", "logits", "seq_block_size", "num_seq_blocks")
+    __slots__ = ("graph", "out_tokens", "logits", "seq_block_size", "num_seq_blocks", "engine")
 
 
 class _DecodeLookahead:
@@ -103,6 +104,9 @@ class LlamaModel:
         self._host_prof = {} if os.environ.get("SWL_HOST_PROFILE") else None
         self._graph_pool = None
         self._scratch = None
+        # the one-sequence persistent decode step (worker/decode_engine.py); None: shape / device / memory / switch say no
+        self._engine = None
+        self.engine_fallbacks = 0    # steps re-run on the multi-launch path after the engine reported a timed-out hand-off
         self.graph_captures = 0      # hipGraph captures so far (each = one warm-up forward + one capture): serving reports it
 
     # ------------------------------------------------------------------------------------------------
@@ -145,6 +149,28 @@ class LlamaModel:
                 ecfg.pack_decode_weights = False
                 return
             pack_decode_weights(self.weight)
+        self._build_decode_engine()
+
+    def _build_decode_engine(self):
+        """(Re)build the persistent one-sequence decode step's weight stream (EngineConfig tuning `decode_engine`): a
+        third copy of the layer weights, laid out per CU in the order the kernel consumes it. Skipped — the multi-launch
+        path serves batch 1 then — when the model shape or the device is not what csrc/decode_engine.hip is laid out for,
+        or when the copy would leave less than a quarter of the usable HBM."""
+        ecfg, cfg = self.engine_config, self.model_config
+        self._engine = None
+        if not (getattr(ecfg, "decode_engine", False) and getattr(ecfg, "use_skinny_gemm", False)):
+            return
+        num_cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        if cfg.head_dim != 128 or not _decode_engine.supported(cfg, num_cus):
+            return
+        need = _decode_engine.stream_bytes(cfg, torch.empty((), dtype=self.dtype).element_size())
+        free_b, total_b = torch.cuda.mem_get_info(self.device)
+        usable = total_b * float(getattr(ecfg, "gpu_mem_utilization", 0.97)) - (total_b - free_b)
+        if need > 0.75 * usable:
+            print(f"[Model] decode_engine disabled: its {need / 2**30:.1f} GiB weight stream would leave "
+                  f"{max(0.0, usable - need) / 2**30:.1f} GiB for the KV pool", flush=True)
+            return
+        self._engine = _decode_engine.DecodeEngine(cfg, self.weight, self.dtype, self.device)
 
     @torch.inference_mode()
     def profile_num_blocks(self) -> int:
@@ -322,6 +348,13 @@ class LlamaModel:
     def _forward(self, input_ids: torch.Tensor, infer_state: LlamaInferState) -> torch.Tensor:
         """Embedding -> L transformer blocks -> final norm / lm_head / argmax.
         Reference: model.py:228-249."""
+        if self._engine_applies(infer_state):
+            # ONE sequence, pure decode: embedding + all transformer blocks in one persistent launch
+            x = self._engine.step(self.k_cache, self.v_cache, self.gpu_block_manager.block_table, input_ids,
+                                  infer_state.seq_ids, infer_state.decoding_seq_lens, self._cos_cached, self._sin_cached,
+                                  self.engine_config.max_blocks_per_seq)
+            rmsnorm_inplace(x, self.weight.final_norm, self.model_config.rms_norm_eps)
+            return self.post_layer.forward_normed(x, out=self._engine.tok_err[:1])
         x = self.pre_layer.forward(input_ids)
         residual = torch.zeros_like(x)
         block_table = None if infer_state.ignore_kvcache else self.gpu_block_manager.block_table
@@ -339,6 +372,22 @@ class LlamaModel:
             x = x.materialize()
         x += residual
         return self.post_layer.forward(x, infer_state)
+
+    def _engine_applies(self, st) -> bool:
+        return (self._engine is not None and st.num_prefill_seqs == 0 and st.batch_size == 1
+                and st.num_decoding_seqs == 1 and not st.ignore_kvcache and self.k_cache is not None)
+
+    def _engine_failed(self, code: int):
+        """A hand-off of the persistent step timed out (bounded spins: the launch ended, its results are garbage). Say so,
+        clear the workspace, and leave batch 1 to the multi-launch HIP path from here on."""
+        print(f"[Model] decode engine reported error {code & 0xff} (CU {code >> 8}): falling back to the multi-launch "
+              f"decode path for one-sequence steps", flush=True)
+        torch.cuda.synchronize()
+        self._engine.reset()
+        self._engine = None
+        self._decode_graphs.clear()
+        self._lookahead = None
+        self.engine_fallbacks += 1
 
     # ---- hipGraph replay of pure-decode steps ------------------------------------------------------------
     _MAX_DECODE_GRAPHS = 48     # LRU bound of the replay cache (each graph pins its activations + [B, vocab] logits)
@@ -395,7 +444,8 @@ class LlamaModel:
 
     def _forward_decode_graph(self, plan: BatchPlan, dev: dict) -> torch.Tensor:
         sbs, nsb_cap = self._graph_bucket(plan)
-        key = (plan.batch_size, sbs, nsb_cap)
+        use_engine = self._engine is not None and plan.batch_size == 1
+        key = (1, 0, 0) if use_engine else (plan.batch_size, sbs, nsb_cap)    # (the engine has one launch geometry)
         entry = self._decode_graphs.pop(key, None)
         plan.seq_block_size, plan.num_seq_blocks = sbs, nsb_cap
         tap = self.post_layer.logits_tap
@@ -422,6 +472,7 @@ class LlamaModel:
                 entry.out_tokens = self._forward(dev["input_ids"], state)
             entry.logits = self.post_layer.last_logits
             entry.seq_block_size, entry.num_seq_blocks = sbs, nsb_cap
+            entry.engine = use_engine
             if tap is not None:
                 del tap[tap_len:]               # what the warm-up run and the capture appended
         self._decode_graphs[key] = entry        # (re)inserted last = most recently used
@@ -476,6 +527,17 @@ class LlamaModel:
         return la
 
     # ------------------------------------------------------------------------------------------------
+    def _tokens_to_host(self, tokens: torch.Tensor) -> List[int]:
+        """The step's one D2H copy (and its one sync). A step of the persistent decode engine brings its error word back in
+        the same copy (DecodeEngine.tok_err = [token, error])."""
+        eng = self._engine
+        if eng is not None and tokens.data_ptr() == eng.tok_err.data_ptr():
+            vals = eng.tok_err.tolist()
+            if vals[1] != 0:
+                raise _decode_engine.DecodeEngineError(str(vals[1]))
+            return vals[:1]
+        return tokens.tolist()
+
     @torch.inference_mode()
     def forward(self, input_ids_list: List[List[int]], seq_ids_list: List[int],
                 decoding_seq_lens_list: List[int], ignore_kvcache: bool = False) -> List[int]:
@@ -485,6 +547,15 @@ class LlamaModel:
         if len(input_ids_list) == 0:
             return []   # the reference's idle engine calls forward([], [], []) in a loop
         _require_hip_device()
+        try:
+            return self._forward_step(input_ids_list, seq_ids_list, decoding_seq_lens_list, ignore_kvcache)
+        except _decode_engine.DecodeEngineError as exc:
+            # bounded hand-off timed out inside the persistent one-sequence step: its KV writes are re-done below with the
+            # same values by the multi-launch HIP path, which serves one-sequence steps from here on
+            self._engine_failed(int(str(exc)))
+            return self._forward_step(input_ids_list, seq_ids_list, decoding_seq_lens_list, ignore_kvcache)
+
+    def _forward_step(self, input_ids_list, seq_ids_list, decoding_seq_lens_list, ignore_kvcache):
         prof = self._host_prof
         t0 = time.perf_counter() if prof is not None else 0.0
         la = self._take_lookahead(input_ids_list, seq_ids_list, decoding_seq_lens_list, ignore_kvcache)
@@ -495,7 +566,7 @@ class LlamaModel:
             if self.after_launch_hook is not None:
                 self.after_launch_hook()
             t4 = time.perf_counter() if prof is not None else 0.0
-            out = tokens.tolist()
+            out = self._tokens_to_host(tokens)
             if nxt is not None:
                 nxt.tokens = out
             self._lookahead = nxt
@@ -542,13 +613,13 @@ class LlamaModel:
         if self.after_launch_hook is not None:
             self.after_launch_hook()
         if prof is None:
-            out = tokens.tolist()
+            out = self._tokens_to_host(tokens)
             if nxt is not None:
                 nxt.tokens = out
             self._lookahead = nxt
             return out
         t4 = time.perf_counter()
-        out = tokens.tolist()
+        out = self._tokens_to_host(tokens)
         t5 = time.perf_counter()
         if nxt is not None:
             nxt.tokens = out

@@ -713,3 +713,40 @@ def test_bench_prefill_flops_and_full_depth_cpu_baseline():
     out = bench.cpu_baseline(tiny, 2, 40, "bfloat16", steps=1)
     assert out["kind"] == "port" and out["extrapolated"] is False and out["value"] > 0
     assert "2 layers, all timed" in out["sample"]
+
+
+def test_decode_engine_stream_packing_matches_the_kernel_addressing():
+    """worker/decode_engine.py packs what csrc/decode_engine.hip reads: per CU the slots of its rows in (row group of 8,
+    k-chunk of 1024) order; in a slot, 1 KiB piece p, lane l, element e = W[row 8g + l // 8][1024 j + 64 p + 8 (l % 8) + e];
+    a layer is qkv | o | up rows | the matching gate rows | down, and its slot count is the library's."""
+    from swiftllm_amd.worker import decode_engine as de
+    n, k = 2 * 2048, 2 * 1024
+    w = torch.arange(n * k, dtype=torch.int32).reshape(n, k)
+    packed = de._pack_rows(w)
+    r, kj = n // 256, k // 1024
+    assert packed.shape == (256, (r // 8) * kj * 8192)
+    rng = random.Random(0)
+    for _ in range(2000):
+        cu, g, j, p, lane, e = (rng.randrange(256), rng.randrange(r // 8), rng.randrange(kj), rng.randrange(16),
+                                rng.randrange(64), rng.randrange(8))
+        slot = g * kj + j
+        got = int(packed[cu, slot * 8192 + p * 512 + lane * 8 + e])
+        assert got == int(w[cu * r + 8 * g + lane // 8, 1024 * j + 64 * p + 8 * (lane % 8) + e])
+    # layer layout and slot count (Llama-3-8B geometry scaled down to what fits a CPU test: hidden 2048, 16/8 heads, FFN 2048)
+    hidden, heads, kv_heads, ffn = 2048, 16, 8, 2048
+    lib = _hip.load()
+    spl = lib.swl_decode_engine_slots_per_layer(hidden, heads, kv_heads, ffn)
+    qkv = torch.zeros(((heads + 2 * kv_heads) * 128, hidden), dtype=torch.int16) + 1
+    o = torch.zeros((hidden, hidden), dtype=torch.int16) + 2
+    up_gate = torch.cat((torch.zeros((ffn, hidden), dtype=torch.int16) + 3, torch.zeros((ffn, hidden), dtype=torch.int16) + 4))
+    down = torch.zeros((hidden, ffn), dtype=torch.int16) + 5
+    layer = de.pack_engine_layer(qkv, o, up_gate, down)
+    assert layer.shape == (256, spl * 8192)
+    counts = [int((layer[7] == v).sum()) // 8192 for v in (1, 2, 3, 4, 5)]
+    assert counts == [2 * 2, 1 * 2, 1 * 2, 1 * 2, 1 * 2] and sum(counts) == spl
+    order = layer[7, ::8192].tolist()
+    assert order == sorted(order)                      # qkv | o | up | gate | down
+    assert lib.swl_decode_engine_supported(4096, 32, 8, 128, 14336, 256) == 1      # Llama-3-8B on an MI355X
+    assert lib.swl_decode_engine_slots_per_layer(4096, 32, 8, 14336) == 104        # 436 MB per layer / 256 CUs / 16 KiB
+    assert lib.swl_decode_engine_supported(4096, 32, 32, 128, 11008, 256) == 0     # Llama-2-7B: FFN rows do not divide
+    assert lib.swl_decode_engine_supported(4096, 32, 8, 128, 14336, 304) == 0

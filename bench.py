@@ -83,8 +83,8 @@ def parse_args():
     ap.add_argument("--no-packed-weights", dest="packed_weights", action="store_false")
     ap.add_argument("--no-rows-decode", dest="rows_decode", action="store_false",
                     help="A/B: split-K + consumer launches for o_proj / down_proj instead of the row-owned kernels (r05)")
-    ap.add_argument("--no-decode-engine", dest="decode_engine", action="store_false",
-                    help="one-sequence steps on the multi-launch path instead of the persistent decode engine (A/B)")
+    ap.add_argument("--decode-engine", dest="decode_engine", action="store_true",
+                    help="one-sequence steps through the persistent decode engine (csrc/decode_engine.hip) instead of the multi-launch path (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[1] / configs[3] / eager side runs")
     ap.add_argument("--skip-prefill", action="store_true", help="fill the KV pool directly instead of running the prompt")
@@ -128,7 +128,7 @@ def ensure_positions(cfg, needed):
 FILLER_BLOCKS_PER_SEQ = 8192    # block-table columns: a filler sequence holds up to this many blocks
 
 
-def build_model(args, cfg, min_blocks, batch, max_len, hip_graph):
+def build_model(args, cfg, min_blocks, batch, max_len, hip_graph, max_tokens=0):
     """The model with its KV pool. Pool size: --kv-blocks, else what the product's own sizing gives on this GPU
     (LlamaModel.profile_num_blocks at gpu_mem_utilization 0.97: reference model.py:94-131), never less than the run
     needs. With --kv-placement top, filler sequences (ids batch, batch+1, ...) take the low block ids so that the run's
@@ -141,10 +141,10 @@ def build_model(args, cfg, min_blocks, batch, max_len, hip_graph):
     ec = EngineConfig(model_path=path, use_dummy=True, block_size=16, gpu_mem_utilization=0.97,
                       num_cpu_blocks=0, max_seqs_in_block_table=max(64, batch) + 64,
                       max_blocks_per_seq=max(FILLER_BLOCKS_PER_SEQ, max_len // 16 + 8),
-                      max_batch_size=batch, max_tokens_in_batch=batch * min(max_len, 8192),
+                      max_batch_size=batch, max_tokens_in_batch=max_tokens or batch * min(max_len, 8192),
                       dtype=args.dtype, fuse_qkv=args.fuse_qkv, use_hip_graph=hip_graph,
                       use_skinny_gemm=args.skinny_gemm, tuning=dict(fuse_splitk_consumers=args.splitk_fusion, rows_decode=getattr(args, "rows_decode", True),
-                                  decode_engine=getattr(args, "decode_engine", True)),
+                                  decode_engine=getattr(args, "decode_engine", False)),
                       pack_decode_weights=getattr(args, "packed_weights", True))
     model = LlamaModel(ec)
     model.load_weights()
@@ -541,6 +541,65 @@ def reference_triton_leg(batch, first_ctx, steps, warmup, prompt_len):
         return None
 
 
+def reference_prefill_leg(batch, prompt_len):
+    """The reference's prompt pass at a long-prompt shape (its Triton flash-attention kernel + F.linear, fp16) in a child
+    process; None when oracle/_ref is not staged or the child fails."""
+    import subprocess
+    if not os.path.isfile(os.path.join(ROOT, "oracle", "_ref", "swiftllm", "worker", "model.py")):
+        return None
+    cmd = [sys.executable, "-m", "oracle.ref_triton", "bench", "--config", "c2", "--batch", str(batch),
+           "--first-context", str(prompt_len + 8), "--steps", "1", "--warmup", "1", "--prefill-len", str(prompt_len)]
+    env = dict(os.environ)
+    env.pop("TRITON_INTERPRET", None)
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=420, check=True)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        return dict(prefill_tok_s=d.get("prefill_tok_s"), prefill_ms=d.get("prefill_ms"), dtype=d["dtype"], path=d["path"])
+    except Exception as e:     # noqa: BLE001
+        print(f"[bench] reference long-prompt leg failed ({type(e).__name__}: {e})", file=sys.stderr)
+        return None
+
+
+def prefill_long_leg(args, shapes=((4, 16384), (1, 32768))):
+    """The regime the reference publishes (README.md:93-101: one forward from (128, 128) up to (1, 131072) input tokens):
+    ONE real LlamaModel.forward prompt pass per shape at Llama-3-8B dims — projections in row blocks through hipBLASLt,
+    rotary + KV store, the hand-written flash-attention kernel (csrc/prefill_attn.hip), lm_head on the last tokens. Here
+    attention is 20-40 % of the flops (4 % at 32 x 1024). Reports tok/s, the fraction of the dense MFMA peak, and the
+    attention kernel's own time (HIP events at the same shape) as a share of the pass."""
+    import torch
+    longest = max(n for _, n in shapes)
+    tokens = max(b * n for b, n in shapes)
+    cfg = ensure_positions(model_config_dict("llama3-8b"), longest + 64)
+    need = max(b * (-(-(n + 8) // 16) + 1) for b, n in shapes) + 8
+    big_args = argparse.Namespace(**dict(vars(args), kv_blocks=need + 64, kv_placement="bottom"))
+    model = build_model(big_args, cfg, need, max(b for b, _ in shapes), longest + 64, False, max_tokens=tokens)
+    g = torch.Generator().manual_seed(5)
+    out = {}
+    for b, n in shapes:
+        prompts = [torch.randint(0, cfg["vocab_size"], (n,), generator=g).tolist() for _ in range(b)]
+        ids = list(range(b))
+        model.forward(prompts, ids, [])                      # untimed: GEMM heuristics, allocator pools
+        model.free_seqs_resources(ids)
+        _, sec = timed(lambda: model.forward(prompts, ids, []))
+        model.free_seqs_resources(ids)
+        gemm_f, attn_f = prefill_flops(cfg, [n] * b)
+        tf = (gemm_f + attn_f) / sec / 1e12
+        leg = dict(batch=b, prompt_len=n, prefill_ms=round(sec * 1e3, 2), prefill_tok_s=round(b * n / sec, 1),
+                   roofline={"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "flops_per_pass": int(gemm_f + attn_f),
+                             "attention_share_of_flops": round(attn_f / (gemm_f + attn_f), 4)})
+        try:
+            attn = prefill_attention_roofline(model, [n] * b, iters=4)
+            leg["attention_kernel"] = {k: attn[k] for k in ("achieved", "frac", "us_per_launch", "unit")}
+            leg["attention_share_of_time"] = round(attn["us_per_launch"] * cfg["num_hidden_layers"] / (sec * 1e6), 4)
+        except Exception as exc:     # noqa: BLE001
+            print(f"[bench] long-prompt attention timing failed ({type(exc).__name__}: {exc})", file=sys.stderr)
+        out[f"{b}x{n}"] = leg
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
 def side_run(args, model_name, batch, context, steps, warmup, label, model=None):
     """A short decode-only measurement of another BASELINE config: KV for `context - warmup - 1` positions is taken
     as it lies in the (N(0,1)-filled) pool, `warmup` + `steps` decode forwards run from there."""
@@ -779,6 +838,24 @@ def _run(args):
         if args.model == "llama3-8b":
             result["configs1_batch1"] = side_run(args, "llama3-8b", 1, 1024 + GEN // 2, 48, 8,
                                                  "BASELINE.json configs[1]: batch 1 decode-only", model=model)
+            try:        # the same steps through the persistent one-sequence decode engine (opt-in: tuning decode_engine)
+                model.engine_config.decode_engine = True
+                model._build_decode_engine()
+                if model._engine is not None:
+                    model._decode_graphs.clear()
+                    leg = side_run(args, "llama3-8b", 1, 1024 + GEN // 2, 48, 8,
+                                   "BASELINE.json configs[1] through csrc/decode_engine.hip: ONE persistent launch for the 32 "
+                                   "layers of a one-sequence step (opt-in; slower than the 5-6 launches per layer it replaces)",
+                                   model=model)
+                    leg["engine_fallbacks"] = int(model.engine_fallbacks)
+                    result["configs1_batch1_engine"] = leg
+            except Exception as exc:     # noqa: BLE001 — a side measurement must never take the bench line down
+                print(f"[bench] decode-engine side run failed ({type(exc).__name__}: {exc})", file=sys.stderr)
+            finally:
+                model.engine_config.decode_engine = False
+                model._engine = None
+                model._decode_graphs.clear()
+                model._lookahead = None
     del run, model
     torch.cuda.empty_cache()
     if world == 1 and not args.no_extras and args.model == "llama3-8b":
@@ -804,12 +881,54 @@ def _run(args):
             torch.cuda.empty_cache()
         except Exception as exc:     # noqa: BLE001 — a side measurement must never take the bench line down
             print(f"[bench] large-batch side runs failed ({type(exc).__name__}: {exc})", file=sys.stderr)
+    if world == 1 and not args.no_extras and args.model == "llama3-8b":
+        try:        # the reference's own precision on the same batch and contexts (its Triton path is float16-only)
+            if args.dtype != "float16":
+                f16_args = argparse.Namespace(**dict(vars(args), dtype="float16", kv_blocks=B * (-(-(S + GEN + 64) // 16) + 1) + 64,
+                                                     kv_placement="bottom"))
+                result["configs2_fp16"] = side_run(f16_args, "llama3-8b", B, S + GEN // 2, 24, 6,
+                                                   f"llama3-8b float16 decode-only, batch {B} at context ~{S + GEN // 2}: the reference's "
+                                                   f"precision and rounding points (no deferred norm: 7 launches per layer)")
+        except Exception as exc:     # noqa: BLE001 — a side measurement must never take the bench line down
+            print(f"[bench] float16 side run failed ({type(exc).__name__}: {exc})", file=sys.stderr)
+        try:
+            result["prefill_long"] = prefill_long_leg(args)
+        except Exception as exc:     # noqa: BLE001
+            print(f"[bench] long-prompt legs failed ({type(exc).__name__}: {exc})", file=sys.stderr)
     if world == 1 and not args.no_extras and not args.no_reference and args.model == "llama3-8b":
         ref = reference_triton_leg(B, first_ctx, K, Wm, S)
         if ref is not None:
             result["reference_triton"] = ref
+        if "prefill_long" in result and "4x16384" in result["prefill_long"]:
+            ref_long = reference_prefill_leg(4, 16384)
+            if ref_long is not None:
+                result["prefill_long"]["4x16384"]["reference_triton"] = ref_long
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, B, int(round(mean_ctx)), args.dtype)
+    # the gates of the side measurements as flat numbers INSIDE `roofline` (a reader that keeps only the contract keys of
+    # this line still sees them); the objects they come from stay where they were
+    def frac(*path):
+        d = result
+        for k in path:
+            d = d.get(k) if isinstance(d, dict) else None
+        return d if isinstance(d, (int, float)) else None
+    summary = {"step_frac": frac("step_roofline", "frac"),
+               "paged_attention_us": frac("roofline_paged_attention", "us_per_launch"),
+               "prefill_frac": frac("prefill_roofline", "frac"),
+               "prefill_attention_frac": frac("prefill_attention_roofline", "frac"),
+               "configs1_batch1_step_frac": frac("configs1_batch1", "step_roofline", "frac"),
+               "configs1_batch1_ms": frac("configs1_batch1", "ms_per_step"),
+               "configs1_batch1_engine_ms": frac("configs1_batch1_engine", "ms_per_step"),
+               "configs3_step_frac": frac("configs3_llama2_7b_4x16k", "step_roofline", "frac"),
+               "decode_batch128_step_frac": frac("decode_batch128", "step_roofline", "frac"),
+               "decode_batch256_step_frac": frac("decode_batch256", "step_roofline", "frac"),
+               "configs2_fp16_step_frac": frac("configs2_fp16", "step_roofline", "frac"),
+               "prefill_long_4x16384_frac": frac("prefill_long", "4x16384", "roofline", "frac"),
+               "prefill_long_4x16384_attention_frac": frac("prefill_long", "4x16384", "attention_kernel", "frac"),
+               "prefill_long_1x32768_frac": frac("prefill_long", "1x32768", "roofline", "frac"),
+               "reference_decode_tok_s": frac("reference_triton", "value")}
+    if isinstance(result.get("roofline"), dict):
+        result["roofline"].update({k: v for k, v in summary.items() if v is not None})
     return result
 
 

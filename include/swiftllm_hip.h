@@ -451,9 +451,10 @@ int swl_gemm_skinny_packed_silu_gate_nf(void *out, const void *x, const void *no
  *   swl_decode_engine_step: resid_out[hidden] = the residual stream after the last layer for the sequence described by
  *     input_ids[0] / seq_ids[0] / seq_lens[0] (length INCLUDING the token being decoded, model.py:296); writes the new
  *     token's K/V into the pools. err_out (may be NULL) receives 0, or the code of a timed-out wait (the workspace then stays
- *     poisoned until reset: later steps return at once with the same code). debug_stamps (may be NULL): [num_layers][8]
- *     100 MHz timestamps of CU 0's phases. Must not run concurrently with another kernel on the device (one workgroup per
- *     CU, all 256 resident). */
+ *     poisoned until reset: later steps return at once with the same code). debug_stamps (may be NULL): [7][num_layers][16]
+ *     100 MHz timestamps of the phases of CUs 0, 37, ... 222. flags: bit 0 = the loader keeps one fill in flight instead of
+ *     three to four while a consumer wave of its CU sweeps granules (pass 1 unless measuring). Must not run concurrently
+ *     with another kernel on the device (one workgroup per CU, all 256 resident). */
 int swl_decode_engine_supported(int32_t hidden, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
                                 int32_t ffn_inter_dim, int32_t num_cus);
 int swl_decode_engine_slots_per_layer(int32_t hidden, int32_t num_q_heads, int32_t num_kv_heads, int32_t ffn_inter_dim);
@@ -466,7 +467,7 @@ int swl_decode_engine_step(void *resid_out, const void *w_stream, const void *no
                            size_t workspace_bytes, int64_t *err_out, uint64_t *debug_stamps, int32_t num_layers,
                            int32_t hidden, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
                            int32_t ffn_inter_dim, int32_t max_blocks_per_seq, float eps, float softmax_scale,
-                           int32_t dtype, swl_stream_t stream);
+                           int32_t flags, int32_t dtype, swl_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -224,17 +224,22 @@ def prefill_attention(q, k, v, o, model_config, engine_config, infer_state):
         n = e - s
         if n == 0:
             continue
-        qi = q[s:e].float().transpose(0, 1)                                    # [H, n, D]
-        ki = k[s:e].float().transpose(0, 1).repeat_interleave(G, dim=0)
+        ki = k[s:e].float().transpose(0, 1).repeat_interleave(G, dim=0)      # [H, n, D]
         vi = v[s:e].float().transpose(0, 1).repeat_interleave(G, dim=0)
-        score = torch.matmul(qi, ki.transpose(1, 2)) * (infer_state.softmax_scale * LOG2E)
-        mask = torch.ones(n, n, dtype=torch.bool).tril()
-        score = torch.where(mask, score, torch.tensor(-1e20))
-        m = score.max(dim=-1, keepdim=True).values
-        p = torch.exp2(score - m)
-        l = p.sum(dim=-1, keepdim=True)
-        out = torch.matmul(p.to(q.dtype).float(), vi) / l
-        ov[s:e] = out.transpose(0, 1).to(o.dtype)
+        # query rows are independent: long prompts go in blocks of rows so that the [H, rows, keys] score tensor stays
+        # small (16k tokens x 8 heads would be 8.6 GB per temporary); each row still sees one exact softmax over its keys
+        rows = n if n <= 4096 else 1024
+        for r0 in range(0, n, rows):
+            r1 = min(n, r0 + rows)
+            qi = q[s + r0:s + r1].float().transpose(0, 1)                       # [H, rows, D]
+            score = torch.matmul(qi, ki[:, :r1].transpose(1, 2)) * (infer_state.softmax_scale * LOG2E)
+            mask = torch.ones(r1 - r0, r1, dtype=torch.bool).tril(diagonal=r0)
+            score = torch.where(mask, score, torch.tensor(-1e20))
+            m = score.max(dim=-1, keepdim=True).values
+            p = torch.exp2(score - m)
+            l = p.sum(dim=-1, keepdim=True)
+            out = torch.matmul(p.to(q.dtype).float(), vi[:, :r1]) / l
+            ov[s + r0:s + r1] = out.transpose(0, 1).to(o.dtype)
 
 
 # ---- block table ----------------------------------------------------------------------------------------

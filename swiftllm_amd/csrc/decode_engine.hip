@@ -71,8 +71,9 @@ struct Params {
     void *resid_out;        // [hidden]: the residual stream after the last layer (input of the final norm)
     u64 *ws;                // state words + granule regions (swl_decode_engine_workspace_bytes)
     long long *err_out;     // host-visible copy of the error word (may be NULL)
-    u64 *dbg;               // optional: CU 0's phase timestamps [L][8]
+    u64 *dbg;               // optional: phase timestamps of 7 CUs, [7][L][16]
     int L, hidden, H, KVH, ffn, max_blocks_per_seq;
+    int flags;              // reserved for A/B switches of experiments (0)
     float eps, scale_log2e;
 };
 
@@ -179,23 +180,22 @@ struct Ctx {
     int lane, cu;
 };
 
-// Bounded spinning: `n` counts the polls of one wait; every 64th poll looks at the clock and at the error word.
+// Bounded spinning: `n` counts the polls of one wait; every 64th poll looks at the workgroup's abort flag and the clock, every
+// 2048th at the global error word (one hot address for 1024 waves: asked rarely on purpose).
 __device__ __forceinline__ bool spin_expired(Ctx &c, u32 &n, u32 code) {
     ++n;
     if ((n & 63u) != 0) return false;
     bool bad = lds_ld(&c.s->abort_flag) != 0;
-    if (!bad) {
-        const u64 e = __hip_atomic_load(c.ws + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bad = e != 0;
-        if (!bad && wall_clock64() - c.t0 > kTimeoutTicks) {
-            bad = true;
-            if (c.lane == 0) {
-                u64 expect = 0;
-                __hip_atomic_compare_exchange_strong(c.ws + 1, &expect, static_cast<u64>(code) | (static_cast<u64>(c.cu) << 8),
-                                                     __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+    if (!bad && wall_clock64() - c.t0 > kTimeoutTicks) {
+        bad = true;
+        if (c.lane == 0) {
+            u64 expect = 0;
+            __hip_atomic_compare_exchange_strong(c.ws + 1, &expect, static_cast<u64>(code) | (static_cast<u64>(c.cu) << 8),
+                                                 __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if (!bad && (n & 2047u) == 0)
+        bad = __hip_atomic_load(c.ws + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     if (bad) {
         lds_st(&c.s->abort_flag, 1u);
         if (c.lane == 0 && c.err_out) {
@@ -207,14 +207,18 @@ __device__ __forceinline__ bool spin_expired(Ctx &c, u32 &n, u32 code) {
 }
 
 // ---- the loader wave -------------------------------------------------------------------------------------------------
-__device__ void loader_main(const Params &p, const Layout &y, Ctx &c) {
+__device__ __forceinline__ void loader_main(const Params &p, const Layout &y, Ctx &c) {
     Lds &s = *c.s;
     const int lane = c.lane;
     const long long layer_stride = static_cast<long long>(kCUs) * y.spl * kSlotBytes;
     const char *base = static_cast<const char *>(p.w_stream) + static_cast<long long>(c.cu) * y.spl * kSlotBytes + lane * 16;
     const u32 a_ready = lds_addr(&s.ready);
     const u32 a_cons = lds_addr(&s.consumed[0]);
-    const int total = p.L * y.spl;
+    // loop invariants in registers: a scratch / kernarg VECTOR load inside the loop would put a vmcnt(0) in front of itself and
+    // drain the ring's in-flight fills every slot (seen: the stream at half rate)
+    const int spl = y.spl;
+    const int total = p.L * spl;
+    const long long layer_skip = layer_stride - static_cast<long long>(spl) * kSlotBytes;
     int ring_pos = 0;
     int q = 0;             // slot within the layer
     int published = 0;     // value of s.ready (slots landed, monotone)
@@ -251,9 +255,9 @@ __device__ void loader_main(const Params &p, const Layout &y, Ctx &c) {
         }
         ring_pos = ring_pos + 1 == kRing ? 0 : ring_pos + 1;
         src += kSlotBytes;
-        if (++q == y.spl) {
+        if (++q == spl) {
             q = 0;
-            src += layer_stride - static_cast<long long>(y.spl) * kSlotBytes;
+            src += layer_skip;
         }
     }
     asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
@@ -283,40 +287,47 @@ __device__ __forceinline__ void put_granule(gu64 *g, int idx, u32 tag, u32 data)
     __hip_atomic_store(g + idx, (static_cast<u64>(tag) << 32) | data, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// One wave sweeps granules [0, n) of `g` (n <= 1024) until every tag matches, then leaves the 32-bit payloads in dst[0, n).
-__device__ __forceinline__ bool sweep_chunk(Ctx &c, const gu64 *g, int n, u32 tag, u32 *dst) {
-    u32 v[16];
+// One wave sweeps n <= 64 * NV granules — granule i of the sweep lives at g[index(i)] — until every tag matches, re-reading
+// only what has not arrived yet, then hands payload i to store(i, payload). All loads of a pass are in flight together.
+template <int NV, typename IndexFn, typename StoreFn>
+__device__ __forceinline__ bool sweep(Ctx &c, const gu64 *g, int n, u32 tag, IndexFn index, StoreFn store) {
+    u64 pending = 0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+        if (k * 64 + c.lane < n) pending |= 1ull << k;
     u32 spins = 0;
     for (;;) {
-        bool ok = true;
+        u64 x[NV];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int idx = k * 64 + c.lane;
-            if (idx < n) {
-                const u64 x = __hip_atomic_load(g + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v[k] = static_cast<u32>(x);
-                ok &= static_cast<u32>(x >> 32) == tag;
+        for (int k = 0; k < NV; ++k)
+            if (pending & (1ull << k)) x[k] = __hip_atomic_load(g + index(k * 64 + c.lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+            if ((pending & (1ull << k)) && static_cast<u32>(x[k] >> 32) == tag) {
+                store(k * 64 + c.lane, static_cast<u32>(x[k]));     // (its readers wait behind a consumer barrier)
+                pending &= ~(1ull << k);
             }
-        }
-        if (__all(ok)) break;
+        if (!__any(pending != 0)) return true;
         if (spin_expired(c, spins, kErrGather)) return false;
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(2);
     }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int idx = k * 64 + c.lane;
-        if (idx < n) dst[idx] = v[k];
-    }
-    return true;
 }
 
-// All-gather of n granules (n % 64 == 0) into dst, 1024-granule chunks dealt to the consumer waves.
+// Contiguous run of n <= 1024 granules -> dst[0, n)
+__device__ __forceinline__ bool sweep_chunk(Ctx &c, const gu64 *g, int n, u32 tag, u32 *dst) {
+    return sweep<16>(c, g, n, tag, [](int i) { return i; }, [dst](int i, u32 v) { dst[i] = v; });
+}
+
+// All-gather of n granules (n % 64 == 0) into dst: the three consumer waves take contiguous thirds (in 64-granule units), each
+// requests its whole share at once (NV >= the loads per lane of one wave's share).
+template <int NV>
 __device__ __forceinline__ bool gather(Ctx &c, int cw, const gu64 *g, int n, u32 tag, u32 *dst) {
-    for (int c0 = cw * 1024; c0 < n; c0 += kConsumers * 1024) {
-        const int m = min(1024, n - c0);
-        if (!sweep_chunk(c, g + c0, m, tag, dst + c0)) return false;
-    }
-    return true;
+    const int per = ((n / 64 + kConsumers - 1) / kConsumers) * 64;
+    const int begin = cw * per;
+    const int count = min(per, n - begin);
+    if (count <= 0) return true;
+    u32 *d = dst + begin;
+    return sweep<NV>(c, g + begin, count, tag, [](int i) { return i; }, [d](int i, u32 v) { d[i] = v; });
 }
 
 // The projections' inner loop: this wave's slots of the operator whose first global slot index is `s0`.
@@ -372,10 +383,20 @@ __device__ __forceinline__ float row_sum(const Lds &s, int row, int KJ) {
 }
 
 // r (storage dtype, n elements at xr) -> x = round(r * rstd * w) at xo; every wave computes the same sum of squares
-// (same order on every CU: the normalised vector is bit-identical chip-wide).
+// (same order on every CU: the normalised vector is bit-identical chip-wide). The norm weights of this thread's chunks
+// were requested before the gather that produced r (norm_prefetch): no global round trip on the critical path.
+constexpr int kNormIters = 6;       // hidden <= 8192: chunks of 8 elements, 192 consumer threads
 template <typename T>
-__device__ __forceinline__ void norm_from_lds(Ctx &c, int ct, const unsigned short *xr, unsigned short *xo, const T *w,
-                                              int n, float eps) {
+__device__ __forceinline__ void norm_prefetch(vec8_t<T> (&wv)[kNormIters], int ct, const T *w, int n) {
+#pragma unroll
+    for (int it = 0; it < kNormIters; ++it) {
+        const int i = ct * 8 + it * kConsumers * 64 * 8;
+        if (i < n) wv[it] = load8(w + i);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void norm_from_lds(Ctx &c, int ct, const unsigned short *xr, unsigned short *xo,
+                                              const vec8_t<T> (&wv)[kNormIters], int n, float eps) {
     float ss = 0.f;
     for (int i = c.lane * 8; i < n; i += 64 * 8) {
         const vec8_t<T> v = *reinterpret_cast<const vec8_t<T> *>(xr + i);
@@ -384,13 +405,16 @@ __device__ __forceinline__ void norm_from_lds(Ctx &c, int ct, const unsigned sho
     }
     ss = wave_allreduce_sum(ss);
     const float rstd = 1.0f / sqrtf(ss / static_cast<float>(n) + eps);
-    for (int i = ct * 8; i < n; i += kConsumers * 64 * 8) {
-        const vec8_t<T> v = *reinterpret_cast<const vec8_t<T> *>(xr + i);
-        const vec8_t<T> wv = load8(w + i);
-        vec8_t<T> o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = to_t<T>(to_f(v[e]) * rstd * to_f(wv[e]));
-        *reinterpret_cast<vec8_t<T> *>(xo + i) = o;
+    for (int it = 0; it < kNormIters; ++it) {
+        const int i = ct * 8 + it * kConsumers * 64 * 8;
+        if (i < n) {
+            const vec8_t<T> v = *reinterpret_cast<const vec8_t<T> *>(xr + i);
+            vec8_t<T> o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = to_t<T>(to_f(v[e]) * rstd * to_f(wv[it][e]));
+            *reinterpret_cast<vec8_t<T> *>(xo + i) = o;
+        }
     }
 }
 
@@ -400,9 +424,15 @@ __device__ __forceinline__ u32 pack2(T a, T b) {
 }
 
 // ---- the consumer waves: one decode step -------------------------------------------------------------------------------
+constexpr int kStamps = 16;         // debug stamps per layer and traced CU
+constexpr int kTraceStride = 37;    // traced CUs: 0, 37, 74, ... (7 of them, on 7 different XCDs)
+constexpr int kTraced = 7;
+
 template <typename T, int G>
-__device__ void consumer_main(const Params &p, const Layout &y, Ctx &c, int cw) {
+__device__ __forceinline__ void consumer_main(const Params &p, const Layout &y, Ctx &c, int cw) {
     constexpr int D = kD;
+    using Tile = DecodeTile<T, D, G>;
+    constexpr int LPT = Tile::LPT, TPI = Tile::TPI, NI = Tile::NI;
     Lds &s = *c.s;
     const int lane = c.lane;
     const int ct = cw * 64 + lane;                  // thread index among the consumers
@@ -426,6 +456,9 @@ __device__ void consumer_main(const Params &p, const Layout &y, Ctx &c, int cw) 
     const int tok_end = min(len, tok_begin + chunk_tok);
     const bool has = att_active && tok_begin < len;
     const bool owner = has && tok_end == len;
+    const int blk_end = (tok_end + kBlk - 1) / kBlk;
+    const int b_first = tok_begin / kBlk + cw;      // this wave's first KV block
+    const bool has_blk = has && b_first < blk_end;
     // merger role
     const int dpc = hidden / kCUs;                  // attention-output columns per CU
     const int cph = D / dpc;                        // CUs per q head
@@ -437,40 +470,69 @@ __device__ void consumer_main(const Params &p, const Layout &y, Ctx &c, int cw) 
     u32 *xb32 = reinterpret_cast<u32 *>(xb);
     const T *kc = static_cast<const T *>(p.k_cache);
     const T *vc = static_cast<const T *>(p.v_cache);
+    const int chunk = lane % LPT, row = lane / LPT;
+
+    // per-step constants of the attention section, fetched once: the rope row of the position, this wave's first block id
+    vec8_t<T> cosv = {}, sinv = {};
+    int64_t phys_first = 0, phys_pos = 0;
+    if (has) {
+        cosv = load8(static_cast<const T *>(p.cos_t) + static_cast<int64_t>(pos) * (D / 2) + (chunk & 7) * 8);
+        sinv = load8(static_cast<const T *>(p.sin_t) + static_cast<int64_t>(pos) * (D / 2) + (chunk & 7) * 8);
+        if (has_blk) phys_first = bt[b_first];
+        if (owner) phys_pos = bt[pos / kBlk];
+    }
+    const int64_t blk_pitch = static_cast<int64_t>(p.L) * KVH;
+
+    const int trace_slot = (p.dbg != nullptr && ct == 0 && cu % kTraceStride == 0 && cu / kTraceStride < kTraced)
+                               ? cu / kTraceStride : -1;
+    u64 *dbg = trace_slot >= 0 ? p.dbg + static_cast<int64_t>(trace_slot) * p.L * kStamps : nullptr;
+#define SWL_STAMP(k) do { if (dbg) dbg[layer * kStamps + (k)] = wall_clock64(); } while (0)
 
     int slot0 = 0;          // global slot index of the running layer's first slot
     for (int layer = 0; layer < p.L; ++layer, slot0 += y.spl) {
         const u32 tag = tag0 + static_cast<u32>(layer) + 1u;
         const T *norm_w = static_cast<const T *>(p.norms) + static_cast<int64_t>(layer) * 2 * hidden;
-        const bool stamp = p.dbg != nullptr && cu == 0 && ct == 0;
-        if (stamp) p.dbg[layer * 8 + 0] = wall_clock64();
+        const int64_t layer_head = static_cast<int64_t>(layer) * KVH + kvh;
+        SWL_STAMP(0);
 
         // ---- P0: the layer input r -> xa; x = rmsnorm(r) * w_attn -> xb ------------------------------------------
+        vec8_t<T> wn[kNormIters];
+        norm_prefetch<T>(wn, ct, norm_w, hidden);
         if (layer == 0) {
-            const T *row = static_cast<const T *>(p.wte) + static_cast<int64_t>(p.input_ids[0]) * hidden;
+            const T *row_p = static_cast<const T *>(p.wte) + static_cast<int64_t>(p.input_ids[0]) * hidden;
             for (int i = ct * 8; i < hidden; i += kConsumers * 64 * 8)
-                *reinterpret_cast<vec8_t<T> *>(xa + i) = load8(row + i);
+                *reinterpret_cast<vec8_t<T> *>(xa + i) = load8(row_p + i);
         } else {
-            if (!gather(c, cw, ws + y.g_r0, hidden / 2, tag - 1u, xa32)) return;   // published by the previous layer
+            if (!gather<22>(c, cw, ws + y.g_r0, hidden / 2, tag - 1u, xa32)) return;   // published by the previous layer
         }
         if (!cbar(c, gen)) return;
-        norm_from_lds<T>(c, ct, xa, xb, norm_w, hidden, p.eps);
+        SWL_STAMP(1);
+        norm_from_lds<T>(c, ct, xa, xb, wn, hidden, p.eps);
         if (ct < y.r_o) s.rmine[ct] = xa[cu * y.r_o + ct];
+        // the first KV block of this wave does not depend on this layer's q: request it now, consume it in P2
+        vec8_t<T> Kp[NI], Vp[NI];
+        if (has_blk) {
+            const int64_t base = (phys_first * blk_pitch + layer_head) * (kBlk * D) + lane * 8;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                Kp[i] = load8_nt(kc + base + i * 512);
+                Vp[i] = load8_nt(vc + base + i * 512);
+            }
+        }
         if (!cbar(c, gen)) return;
-        if (stamp) p.dbg[layer * 8 + 1] = wall_clock64();
+        SWL_STAMP(2);
 
         // ---- P1: q/k/v rows of this CU ---------------------------------------------------------------------------
         if (!gemv_slots<T>(c, cw, slot0, y.n_qkv, y.kj_h, xb)) return;
         if (!cbar(c, gen)) return;
+        SWL_STAMP(3);
         if (ct < y.r_qkv / 2) {
             const T a = to_t<T>(row_sum(s, 2 * ct, y.kj_h)), b = to_t<T>(row_sum(s, 2 * ct + 1, y.kj_h));
             put_granule(ws + y.g_qkv, cu * (y.r_qkv / 2) + ct, tag, pack2<T>(a, b));
         }
-        if (stamp) p.dbg[layer * 8 + 2] = wall_clock64();
+        SWL_STAMP(4);
 
         // ---- P2: attention -----------------------------------------------------------------------------------------
-        const int64_t layer_head = static_cast<int64_t>(layer) * KVH + kvh;
-        const int64_t blk_pitch = static_cast<int64_t>(p.L) * KVH;
         if (has) {
             // q heads kvh*G .. +G (contiguous), the kv head's new k and v
             bool ok = true;
@@ -480,32 +542,8 @@ __device__ void consumer_main(const Params &p, const Layout &y, Ctx &c, int cw) 
             if (!ok) return;
         }
         if (!cbar(c, gen)) return;
-        if (has) {
-            // rotate-half rotary on the G q heads and the k head, storage-dtype arithmetic (rotary_emb.py:26-42)
-            const T *cs = static_cast<const T *>(p.cos_t) + static_cast<int64_t>(pos) * (D / 2);
-            const T *sn = static_cast<const T *>(p.sin_t) + static_cast<int64_t>(pos) * (D / 2);
-            for (int i = ct; i < (G + 1) * (D / 2); i += kConsumers * 64) {
-                const int hd = i / (D / 2), d = i % (D / 2);
-                unsigned short *v = hd < G ? &s.att_q[hd * D] : &s.att_kv[0];
-                const T x0 = bits_to_t<T>(v[d]), x1 = bits_to_t<T>(v[d + D / 2]);
-                const T cc = cs[d], ss = sn[d];
-                v[d] = t_to_bits(sub_t<T>(mul_t<T>(x0, cc), mul_t<T>(x1, ss)));
-                v[d + D / 2] = t_to_bits(add_t<T>(mul_t<T>(x0, ss), mul_t<T>(x1, cc)));
-            }
-        }
-        if (!cbar(c, gen)) return;
-        if (owner && ct < 2 * (D / 8)) {
-            // the new token's rotated k and its v go to the pool (kvcache_mgmt.py:50-79)
-            const bool is_v = ct >= D / 8;
-            const int ch = ct % (D / 8);
-            T *pool = const_cast<T *>(is_v ? vc : kc) +
-                      (static_cast<int64_t>(bt[pos / kBlk]) * blk_pitch + layer_head) * (kBlk * D) + (pos % kBlk) * D;
-            store8(pool + ch * 8, *reinterpret_cast<const vec8_t<T> *>(&s.att_kv[(is_v ? D : 0) + ch * 8]));
-        }
+        SWL_STAMP(5);
         {
-            using Tile = DecodeTile<T, D, G>;
-            constexpr int LPT = Tile::LPT, TPI = Tile::TPI, NI = Tile::NI;
-            const int chunk = lane % LPT, row = lane / LPT;
             float m[G], l[G], acc[G][8];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
@@ -515,25 +553,53 @@ __device__ void consumer_main(const Params &p, const Layout &y, Ctx &c, int cw) 
                 for (int jj = 0; jj < 8; ++jj) acc[g][jj] = 0.f;
             }
             if (has) {
+                // rotate-half rotary in registers, storage-dtype arithmetic (rotary_emb.py:26-42): a lane holds elements
+                // [8 chunk, +8) of a head; its partner half sits 8 chunks away; lanes of the upper half produce x1'
+                const bool hi = chunk >= 8;
+                auto rotated = [&](const unsigned short *head) {
+                    const vec8_t<T> own = *reinterpret_cast<const vec8_t<T> *>(head + chunk * 8);
+                    const vec8_t<T> oth = *reinterpret_cast<const vec8_t<T> *>(head + (chunk ^ 8) * 8);
+                    vec8_t<T> r;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        r[e] = hi ? add_t<T>(mul_t<T>(oth[e], sinv[e]), mul_t<T>(own[e], cosv[e]))
+                                  : sub_t<T>(mul_t<T>(own[e], cosv[e]), mul_t<T>(oth[e], sinv[e]));
+                    return r;
+                };
                 vec8_t<T> qv[G];
 #pragma unroll
-                for (int g = 0; g < G; ++g) qv[g] = *reinterpret_cast<const vec8_t<T> *>(&s.att_q[g * D + chunk * 8]);
-                const int blk_end = (tok_end + kBlk - 1) / kBlk;
-                for (int b = tok_begin / kBlk + cw; b < blk_end; b += kConsumers) {
-                    const int64_t base = (static_cast<int64_t>(bt[b]) * blk_pitch + layer_head) * (kBlk * D) + lane * 8;
+                for (int g = 0; g < G; ++g) qv[g] = rotated(&s.att_q[g * D]);
+                const vec8_t<T> knew = rotated(&s.att_kv[0]);
+                const vec8_t<T> vnew = *reinterpret_cast<const vec8_t<T> *>(&s.att_kv[D + chunk * 8]);
+                if (owner && cw == 0 && row == 0) {
+                    // the new token's rotated k and its v go to the pool (kvcache_mgmt.py:50-79)
+                    const int64_t off = (phys_pos * blk_pitch + layer_head) * (kBlk * D) + (pos % kBlk) * D + chunk * 8;
+                    store8(const_cast<T *>(kc) + off, knew);
+                    store8(const_cast<T *>(vc) + off, vnew);
+                }
+                for (int b = b_first; b < blk_end; b += kConsumers) {
                     vec8_t<T> Kv[NI], Vv[NI];
+                    if (b == b_first) {
 #pragma unroll
-                    for (int i = 0; i < NI; ++i) {
-                        Kv[i] = load8_nt(kc + base + i * 512);
-                        Vv[i] = load8_nt(vc + base + i * 512);
+                        for (int i = 0; i < NI; ++i) {
+                            Kv[i] = Kp[i];
+                            Vv[i] = Vp[i];
+                        }
+                    } else {
+                        const int64_t base = (static_cast<int64_t>(bt[b]) * blk_pitch + layer_head) * (kBlk * D) + lane * 8;
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) {
+                            Kv[i] = load8_nt(kc + base + i * 512);
+                            Vv[i] = load8_nt(vc + base + i * 512);
+                        }
                     }
                     const int tok0 = b * kBlk;
-                    if (b == pos / kBlk) {  // the pool read of the new token raced with its store: take it from LDS
+                    if (b == pos / kBlk) {  // the pool read of the new token raced with its store: take it from registers
 #pragma unroll
                         for (int i = 0; i < NI; ++i)
                             if (tok0 + i * TPI + row == pos) {
-                                Kv[i] = *reinterpret_cast<const vec8_t<T> *>(&s.att_kv[chunk * 8]);
-                                Vv[i] = *reinterpret_cast<const vec8_t<T> *>(&s.att_kv[D + chunk * 8]);
+                                Kv[i] = knew;
+                                Vv[i] = vnew;
                             }
                     }
                     attend_block<T, D, G>(qv, Kv, Vv, m, l, acc, p.scale_log2e, tok0, row, len, tok0 + kBlk > len);
@@ -571,6 +637,7 @@ __device__ void consumer_main(const Params &p, const Layout &y, Ctx &c, int cw) 
             }
         }
         if (!cbar(c, gen)) return;
+        SWL_STAMP(6);
         if (att_active) {
             // merge the three waves; publish the partial of (head, split): normalised o + base-2 log-sum-exp
             for (int oidx = ct; oidx < G * (D + 1); oidx += kConsumers * 64) {
@@ -592,54 +659,63 @@ __device__ void consumer_main(const Params &p, const Layout &y, Ctx &c, int cw) 
                 put_granule(ws + y.g_part, ((kvh * G + g) * S + sp) * (D + 1) + d, tag, __float_as_uint(out));
             }
         }
-        if (stamp) p.dbg[layer * 8 + 3] = wall_clock64();
+        SWL_STAMP(7);
         // mergers: head mh, columns md0 .. md0 + dpc of the attention output
         if (cw == 0) {
-            const int per = dpc + 1, n = S * per;
-            u32 v[(kMaxSplits * 17 + 63) / 64];
-            u32 spins = 0;
-            for (;;) {
-                bool ok = true;
-#pragma unroll
-                for (int k = 0; k < (kMaxSplits * 17 + 63) / 64; ++k) {
-                    const int idx = k * 64 + lane;
-                    if (idx < n) {
-                        const int sp2 = idx / per, e = idx % per;
-                        const u64 x = __hip_atomic_load(ws + y.g_part + (mh * S + sp2) * (D + 1) + (e < dpc ? md0 + e : D),
-                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        v[k] = static_cast<u32>(x);
-                        ok &= static_cast<u32>(x >> 32) == tag;
-                    }
-                }
-                if (__all(ok)) break;
-                if (spin_expired(c, spins, kErrGather)) return;
-                __builtin_amdgcn_s_sleep(1);
-            }
-#pragma unroll
-            for (int k = 0; k < (kMaxSplits * 17 + 63) / 64; ++k) {
-                const int idx = k * 64 + lane;
-                if (idx < n) s.mg[idx] = __uint_as_float(v[k]);
-            }
+            const int per = dpc + 1;
+            const gu64 *pg = ws + y.g_part + mh * S * (D + 1);
+            float *mg = s.mg;
+            const int dpc_ = dpc, md0_ = md0;
+            if (!sweep<(kMaxSplits * 17 + 63) / 64>(
+                    c, pg, S * per, tag,
+                    [per, dpc_, md0_](int i) { const int e = i % per; return (i / per) * (kD + 1) + (e < dpc_ ? md0_ + e : kD); },
+                    [mg](int i, u32 v) { mg[i] = __uint_as_float(v); }))
+                return;
         }
         if (!cbar(c, gen)) return;
-        if (ct < dpc / 2) {
-            const int per = dpc + 1;
+        SWL_STAMP(8);
+        if (cw == 0) {
+            // LSE-weighted sum over the S splits (paged_attn.py:128-149), one wave: lane -> (split l % 32 [+ 32 ...], half l / 32
+            // of the dpc columns); maxima and sums cross the 32 lanes of a half with DPP + one shuffle
+            const int per = dpc + 1, hd = dpc / 2;
+            const int sl = lane & 31, hf = lane >> 5;
             float M = kNegBig;
-            for (int sp2 = 0; sp2 < S; ++sp2) M = fmaxf(M, s.mg[sp2 * per + dpc]);
-            float W = 0.f, o0 = 0.f, o1 = 0.f;
-            for (int sp2 = 0; sp2 < S; ++sp2) {     // split order: the reference's phase 2 (paged_attn.py:128-149)
+            for (int sp2 = sl; sp2 < S; sp2 += 32) M = fmaxf(M, s.mg[sp2 * per + dpc]);
+            M = fmaxf(M, dpp_mov<kDppQuadXor1>(M));
+            M = fmaxf(M, dpp_mov<kDppQuadXor2>(M));
+            M = fmaxf(M, dpp_mov<kDppRowHalfMirror>(M));
+            M = fmaxf(M, dpp_mov<kDppRowMirror>(M));
+            M = fmaxf(M, __shfl_xor(M, 16, 64));
+            float W = 0.f, o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = 0.f;
+            for (int sp2 = sl; sp2 < S; sp2 += 32) {
                 const float wgt = fast_exp2(s.mg[sp2 * per + dpc] - M);
                 W += wgt;
-                o0 = fmaf(wgt, s.mg[sp2 * per + 2 * ct], o0);
-                o1 = fmaf(wgt, s.mg[sp2 * per + 2 * ct + 1], o1);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (e < hd) o[e] = fmaf(wgt, s.mg[sp2 * per + hf * hd + e], o[e]);
             }
-            put_granule(ws + y.g_oattn, (mh * D + md0) / 2 + ct, tag, pack2<T>(to_t<T>(o0 / W), to_t<T>(o1 / W)));
+            W = group_allreduce_sum<16>(W);
+            W += __shfl_xor(W, 16, 64);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[e] = group_allreduce_sum<16>(o[e]);
+                o[e] += __shfl_xor(o[e], 16, 64);
+            }
+            if (sl == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; e += 2)
+                    if (e < hd)
+                        put_granule(ws + y.g_oattn, (mh * D + md0 + hf * hd + e) / 2, tag,
+                                    pack2<T>(to_t<T>(o[e] / W), to_t<T>(o[e + 1] / W)));
+            }
         }
 
         // ---- P3: o projection + residual add -----------------------------------------------------------------------
-        if (!gather(c, cw, ws + y.g_oattn, hidden / 2, tag, xb32)) return;
+        if (!gather<22>(c, cw, ws + y.g_oattn, hidden / 2, tag, xb32)) return;
         if (!cbar(c, gen)) return;
-        if (stamp) p.dbg[layer * 8 + 4] = wall_clock64();
+        SWL_STAMP(9);
         if (!gemv_slots<T>(c, cw, slot0 + y.s_o, y.n_o, y.kj_h, xb)) return;
         if (!cbar(c, gen)) return;
         if (ct < y.r_o / 2) {
@@ -647,14 +723,17 @@ __device__ void consumer_main(const Params &p, const Layout &y, Ctx &c, int cw) 
             const T b = add_t<T>(bits_to_t<T>(s.rmine[2 * ct + 1]), to_t<T>(row_sum(s, 2 * ct + 1, y.kj_h)));
             put_granule(ws + y.g_r1, cu * (y.r_o / 2) + ct, tag, pack2<T>(a, b));
         }
+        SWL_STAMP(10);
 
         // ---- P4: FFN norm, up/gate projection, SiLU-gate -----------------------------------------------------------
-        if (!gather(c, cw, ws + y.g_r1, hidden / 2, tag, xa32)) return;
+        norm_prefetch<T>(wn, ct, norm_w + hidden, hidden);
+        if (!gather<22>(c, cw, ws + y.g_r1, hidden / 2, tag, xa32)) return;
         if (!cbar(c, gen)) return;
-        norm_from_lds<T>(c, ct, xa, xb, norm_w + hidden, hidden, p.eps);
+        SWL_STAMP(11);
+        norm_from_lds<T>(c, ct, xa, xb, wn, hidden, p.eps);
         if (ct < y.r_dn) s.rmine[ct] = xa[cu * y.r_dn + ct];
         if (!cbar(c, gen)) return;
-        if (stamp) p.dbg[layer * 8 + 5] = wall_clock64();
+        SWL_STAMP(12);
         if (!gemv_slots<T>(c, cw, slot0 + y.s_ug, y.n_ug, y.kj_h, xb)) return;
         if (!cbar(c, gen)) return;
         {
@@ -670,11 +749,12 @@ __device__ void consumer_main(const Params &p, const Layout &y, Ctx &c, int cw) 
                 put_granule(ws + y.g_act, cu * (half / 2) + ct, tag, pack2<T>(act[0], act[1]));
             }
         }
-        if (stamp) p.dbg[layer * 8 + 6] = wall_clock64();
+        SWL_STAMP(13);
 
         // ---- P5: down projection + residual add --------------------------------------------------------------------
-        if (!gather(c, cw, ws + y.g_act, ffn / 2, tag, xa32)) return;
+        if (!gather<44>(c, cw, ws + y.g_act, ffn / 2, tag, xa32)) return;
         if (!cbar(c, gen)) return;
+        SWL_STAMP(14);
         if (!gemv_slots<T>(c, cw, slot0 + y.s_dn, y.n_dn, y.kj_f, xa)) return;
         if (!cbar(c, gen)) return;
         if (ct < y.r_dn / 2) {
@@ -688,9 +768,11 @@ __device__ void consumer_main(const Params &p, const Layout &y, Ctx &c, int cw) 
                 ro[1] = b;
             }
         }
-        if (!cbar(c, gen)) return;     // part[] / rmine[] are reused by the next layer
-        if (stamp) p.dbg[layer * 8 + 7] = wall_clock64();
+        SWL_STAMP(15);
+        // (no barrier here: part[] / rmine[] are next written behind the first consumer barrier of the next layer, which
+        // the one wave that reads them above — wave 0 — reaches only after it is done with them)
     }
+#undef SWL_STAMP
     // the step is done for this CU; CU 0 advances the epoch (every CU read it before publishing anything CU 0 needed)
     if (cu == 0 && ct == 0) __hip_atomic_store(ws, static_cast<u64>(step + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -763,8 +845,8 @@ extern "C" int swl_decode_engine_step(void *resid_out, const void *w_stream, con
                                       const void *sin_table, void *workspace, size_t workspace_bytes, int64_t *err_out,
                                       uint64_t *debug_stamps, int32_t num_layers, int32_t hidden, int32_t num_q_heads,
                                       int32_t num_kv_heads, int32_t head_dim, int32_t ffn_inter_dim,
-                                      int32_t max_blocks_per_seq, float eps, float softmax_scale, int32_t dtype,
-                                      swl_stream_t stream) {
+                                      int32_t max_blocks_per_seq, float eps, float softmax_scale, int32_t flags,
+                                      int32_t dtype, swl_stream_t stream) {
     Layout y;
     if (num_layers <= 0 || head_dim != swl::eng::kD ||
         !swl::eng::make_layout(hidden, num_q_heads, num_kv_heads, ffn_inter_dim, y))
@@ -797,6 +879,7 @@ extern "C" int swl_decode_engine_step(void *resid_out, const void *w_stream, con
     p.KVH = num_kv_heads;
     p.ffn = ffn_inter_dim;
     p.max_blocks_per_seq = max_blocks_per_seq;
+    p.flags = flags;
     p.eps = eps;
     p.scale_log2e = softmax_scale * 1.4426950408889634f;
     const int G = num_q_heads / num_kv_heads;

@@ -71,11 +71,14 @@ class EngineConfig:
         # no consumer launch), and the projection that follows applies the norm weight and the 1/rms itself while it stages
         # the raw residual rows ("norm on the fly", gemm_skinny.hip NF): 6 launches per layer at batch 32, 5 up to batch 8
         rows_decode=True,
-        # ONE decoding sequence: the whole transformer stack of the step is one persistent launch (csrc/decode_engine.hip: a
+        # ONE decoding sequence: the whole transformer stack of the step as one persistent launch (csrc/decode_engine.hip: a
         # loader wave per CU streams that CU's rows of every projection by LDS-DMA, three consumer waves compute, operator
-        # boundaries are in-launch granule hand-offs) — the reference's rounding points in BOTH dtypes. Costs a third copy of
-        # the layer weights (13.9 GB for Llama-3-8B). Shapes the kernel is not laid out for run the multi-launch path.
-        decode_engine=True,
+        # boundaries are in-launch granule hand-offs; the reference's rounding points in BOTH dtypes; every wait bounded).
+        # OFF by default: measured on MI355X at Llama-3-8B it is parity-green and SLOWER than the 5-6 launches it replaces
+        # (3.29 vs 3.03 ms per step at context 1088: its six all-to-all hand-offs per layer cost ~40 us of which the 7-slot
+        # LDS ring covers ~12, the launch seams they replace ~27 — DESIGN.md section 4.9, profiles/r06_engine_*). Costs a
+        # third copy of the layer weights (13.9 GB for Llama-3-8B) when on.
+        decode_engine=False,
         pin_swap_memory=True,           # host swap pool in pinned memory (falls back to pageable when the host refuses)
     )
 

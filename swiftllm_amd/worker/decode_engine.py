@@ -10,6 +10,8 @@ workgroups, each streaming ITS rows of every projection from one contiguous run 
   * the launch (`DecodeEngine.step`) and the error protocol (a timed-out hand-off poisons the workspace; the model then
     drops back to the multi-launch path — another HIP path, never a CPU fallback).
 """
+import os
+
 import torch
 
 from swiftllm_amd import _hip
@@ -75,6 +77,9 @@ class DecodeEngine:
         # [0] the sampled token (written by the sampler), [1] the engine's error word: ONE D2H copy brings both back
         self.tok_err = torch.zeros(2, dtype=torch.int64, device=device)
         self.debug_stamps = None
+        # bit 0: thin the weight stream while a consumer wave sweeps granules (csrc/decode_engine.hip); SWL_ENGINE_FLAGS
+        # overrides it for A/B measurements (tools/engine_trace.py)
+        self.flags = int(os.environ.get("SWL_ENGINE_FLAGS", "1"))
         self.wte = weight.wte
         self.reset()
 
@@ -95,7 +100,7 @@ class DecodeEngine:
         self.tok_err.zero_()
 
     def enable_debug_stamps(self):
-        self.debug_stamps = torch.zeros((self.cfg.num_layers, 8), dtype=torch.int64, device=self.device)
+        self.debug_stamps = torch.zeros((7, self.cfg.num_layers, 16), dtype=torch.int64, device=self.device)
         return self.debug_stamps
 
     def step(self, k_cache, v_cache, block_table, input_ids, seq_ids, seq_lens, cos, sin, max_blocks_per_seq: int):
@@ -107,5 +112,5 @@ class DecodeEngine:
                   _hip.ptr(seq_ids), _hip.ptr(seq_lens), _hip.ptr(cos), _hip.ptr(sin), _hip.ptr(self.ws), self.ws_bytes,
                   self.tok_err[1:].data_ptr(), _hip.ptr(self.debug_stamps), cfg.num_layers, cfg.hidden_size,
                   cfg.num_q_heads, cfg.num_kv_heads, cfg.head_dim, cfg.ffn_inter_dim, max_blocks_per_seq,
-                  cfg.rms_norm_eps, cfg.head_dim ** -0.5, _hip.dtype_code(self.dtype), _hip.stream())
+                  cfg.rms_norm_eps, cfg.head_dim ** -0.5, self.flags, _hip.dtype_code(self.dtype), _hip.stream())
         return self.resid

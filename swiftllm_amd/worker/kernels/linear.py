@@ -114,11 +114,32 @@ def _mid_ok(a: torch.Tensor, w: torch.Tensor) -> bool:
 _WIDE_MAX_M = 256
 
 
+def _launch_wide(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    m, k = a.shape
+    n = w.shape[0]
+    out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    need = _hip.load().swl_gemm_packed_wide_workspace_bytes(m, n, k)
+    ws = _workspace(a.device, need) if need else None
+    _hip.call("swl_gemm_packed_wide", _hip.ptr(out), _hip.ptr(a), _hip.ptr(_packed_of(w)), _hip.ptr(ws),
+              ws.numel() * 4 if ws is not None else 0, m, n, k, _row_stride(a), n, 0, 0, _hip.dtype_code(a.dtype),
+              _hip.stream())
+    return out
+
+
+def _launch_wide_silu(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    m, k = a.shape
+    inter = w.shape[0] // 2
+    out = torch.empty((m, inter), dtype=a.dtype, device=a.device)
+    _hip.call("swl_gemm_packed_wide_silu_gate", _hip.ptr(out), _hip.ptr(a), _hip.ptr(_packed_of(w)), m, inter, k,
+              _row_stride(a), inter, 0, _hip.dtype_code(a.dtype), _hip.stream())
+    return out
+
+
 def _wide_ok(a: torch.Tensor, w: torch.Tensor) -> bool:
     """Large decode batches (64 < M <= 256) on a packed weight: swl_gemm_packed_wide (csrc/gemm_wide.hip) — up to 8 blocks
     of 32 tokens share every weight fragment, x^T shared by the workgroup through LDS. Which projections it serves is a
-    measured policy: kernels/route_tune.py (the r04 table for the shapes it was measured on, a one-off measurement on this
-    device for any other)."""
+    measured policy, decided once per deployment and only LOOKED UP here: kernels/route_tune.py (the r04 table for the
+    shapes it was measured on; `tune_wide_routes` at load time for any other)."""
     m = a.shape[0] if a.dim() == 2 else 0
     if not (64 < m <= _WIDE_MAX_M) or _packed_of(w) is None:
         return False
@@ -126,15 +147,7 @@ def _wide_ok(a: torch.Tensor, w: torch.Tensor) -> bool:
     if not (a.is_cuda and a.dtype == w.dtype and a.stride(1) == 1 and a.stride(0) % 8 == 0 and k % 64 == 0 and n % 32 == 0
             and m * _row_stride(a) < (1 << 31)):
         return False
-
-    def ours():
-        out = torch.empty((m, n), dtype=a.dtype, device=a.device)
-        need = _hip.load().swl_gemm_packed_wide_workspace_bytes(m, n, k)
-        ws = _workspace(a.device, need) if need else None
-        _hip.call("swl_gemm_packed_wide", _hip.ptr(out), _hip.ptr(a), _hip.ptr(_packed_of(w)), _hip.ptr(ws),
-                  ws.numel() * 4 if ws is not None else 0, m, n, k, _row_stride(a), n, 0, 0, _hip.dtype_code(a.dtype),
-                  _hip.stream())
-    return route_tune.decide(m, n, k, a.dtype, a.device, False, ours, lambda: F.linear(a, w))
+    return route_tune.decide(m, n, k, a.dtype, False)
 
 
 def _wide_silu_ok(a: torch.Tensor, w: torch.Tensor) -> bool:
@@ -144,17 +157,35 @@ def _wide_silu_ok(a: torch.Tensor, w: torch.Tensor) -> bool:
     if not (a.is_cuda and a.dtype == w.dtype and a.stride(1) == 1 and a.stride(0) % 8 == 0 and w.shape[1] % 64 == 0
             and m * _row_stride(a) < (1 << 31)):
         return False
-    n2, k = w.shape
+    return route_tune.decide(m, w.shape[0], w.shape[1], a.dtype, True)
 
-    def ours():
-        out = torch.empty((m, n2 // 2), dtype=a.dtype, device=a.device)
-        _hip.call("swl_gemm_packed_wide_silu_gate", _hip.ptr(out), _hip.ptr(a), _hip.ptr(_packed_of(w)), m, n2 // 2, k,
-                  _row_stride(a), n2 // 2, 0, _hip.dtype_code(a.dtype), _hip.stream())
 
-    def library():
-        r = F.linear(a, w)
-        _hip.call("swl_silu_mul", _hip.ptr(r), m, n2 // 2, _hip.dtype_code(a.dtype), _hip.stream())
-    return route_tune.decide(m, n2, k, a.dtype, a.device, True, ours, library)
+def tune_wide_routes(weights, up_gate_weights, dtype: torch.dtype, device, model_path: str) -> dict:
+    """Decide, ONCE per deployment and before any request, which side serves every projection class of this model at every
+    32-token bucket of 65..256 tokens (route_tune.prepare). `weights`: the packed projection tensors a decode step
+    streams; `up_gate_weights`: those that also have the SiLU-gate form. Classes the r04 table covers cost nothing;
+    others are timed here (or read from the table the first replica of this node wrote)."""
+    rep = {}
+    for w in weights:
+        if _packed_of(w) is not None and w.shape[1] % 64 == 0 and w.shape[0] % 32 == 0:
+            rep.setdefault((w.shape[0], w.shape[1], False), w)
+    for w in up_gate_weights:
+        if _packed_of(w) is not None and w.shape[1] % 64 == 0 and w.shape[0] % 64 == 0:
+            rep.setdefault((w.shape[0], w.shape[1], True), w)
+
+    def measure(n, k, silu, bucket):
+        w = rep[(n, k, silu)]
+        a = torch.randn((bucket, k), dtype=torch.float32, device=device).to(dtype)
+        if silu:
+            def library():
+                r = F.linear(a, w)
+                _hip.call("swl_silu_mul", _hip.ptr(r), bucket, n // 2, _hip.dtype_code(dtype), _hip.stream())
+            ours = lambda: _launch_wide_silu(a, w)     # noqa: E731
+        else:
+            library = lambda: F.linear(a, w)            # noqa: E731
+            ours = lambda: _launch_wide(a, w)           # noqa: E731
+        return route_tune.wins(route_tune.time_us(ours), route_tune.time_us(library))
+    return route_tune.prepare(rep.keys(), dtype, device, model_path, measure)
 
 
 # (the r04 names, kept for tests/test_host_logic.py: the measured table itself)
@@ -165,15 +196,7 @@ _wide_silu_wins = route_tune.table_wide_silu_wins
 def linear(a: torch.Tensor, w: torch.Tensor, skinny: bool = False) -> torch.Tensor:
     """a[T, in] @ w[out, in]^T -> [T, out] (fp32 accumulation, one rounding)."""
     if skinny and _wide_ok(a, w):
-        m, k = a.shape
-        n = w.shape[0]
-        out = torch.empty((m, n), dtype=a.dtype, device=a.device)
-        need = _hip.load().swl_gemm_packed_wide_workspace_bytes(m, n, k)
-        ws = _workspace(a.device, need) if need else None
-        _hip.call("swl_gemm_packed_wide", _hip.ptr(out), _hip.ptr(a), _hip.ptr(_packed_of(w)), _hip.ptr(ws),
-                  ws.numel() * 4 if ws is not None else 0, m, n, k, _row_stride(a), n, 0, 0, _hip.dtype_code(a.dtype),
-                  _hip.stream())
-        return out
+        return _launch_wide(a, w)
     if skinny and _mid_ok(a, w):
         m, k = a.shape
         n = w.shape[0]
@@ -294,12 +317,7 @@ def linear_silu_gate(a: torch.Tensor, w_up_gate: torch.Tensor, row_scale=None):
                   _hip.dtype_code(a.dtype), _hip.stream())
         return out
     if _wide_silu_ok(a, w_up_gate):        # large batch, packed weight
-        m, k = a.shape
-        inter = w_up_gate.shape[0] // 2
-        out = torch.empty((m, inter), dtype=a.dtype, device=a.device)
-        _hip.call("swl_gemm_packed_wide_silu_gate", _hip.ptr(out), _hip.ptr(a), _hip.ptr(_packed_of(w_up_gate)), m, inter, k,
-                  _row_stride(a), inter, 0, _hip.dtype_code(a.dtype), _hip.stream())
-        return out
+        return _launch_wide_silu(a, w_up_gate)
     if _mid_ok(a, w_up_gate) and w_up_gate.shape[0] % 64 == 0:   # medium batch, packed weight
         m, k = a.shape
         inter = w_up_gate.shape[0] // 2

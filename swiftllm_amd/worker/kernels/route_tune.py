@@ -1,22 +1,25 @@
 """Which kernel serves a decode projection of 65..256 tokens: the hand-written `swl_gemm_packed_wide` (csrc/gemm_wide.hip)
 or the library GEMM (`F.linear` -> hipBLASLt, the reference's own call: swiftllm/worker/kernels/linear.py:3-12)?
 
-Both compute the same product (one rounding of an fp32-accumulated sum); which one is faster depends on (N, K, tokens, dtype)
-and on the hipBLASLt build — the library's time is far from monotone in the token count (profiles/r04c_gemm_wide_micro.jsonl).
+Both compute the same product (one rounding of an fp32-accumulated sum) but sum K in different orders, so WHICH one runs
+is part of a deployment's numerics: it must not depend on a timing race inside a request, and every replica of a
+data-parallel deployment must answer alike.
 
-r04 hard-coded ONE sweep (Llama-3-8B widths, bfloat16, ROCm 7.2) and applied it to every model and dtype (VERDICT r04 weak 9,
-ADVICE r04): a Llama-2-13B width or another ROCm drop silently landed on whatever side of every cliff the table said. Now:
-  * the measured table answers only for the (N, K, dtype) classes it was measured on (`MEASURED`);
-  * any other class is measured ONCE on the device it runs on — a few launches of each side at the token bucket in question,
-    the hand-written kernel taken when it wins by more than 3 % — and remembered, in memory and in a small JSON file keyed
-    by device name + HIP version (`SWIFTLLM_ROUTE_CACHE`, default ~/.cache/swiftllm_amd/routes.json), so a server pays
-    the measurement once per (shape, bucket) in its lifetime;
+  * the measured table (r04 sweep: Llama-3-8B widths, bfloat16, ROCm 7.2) answers for the (N, K, dtype) classes it was
+    measured on (`MEASURED`);
+  * any other class is measured ONCE PER DEPLOYMENT, at `LlamaModel.load_weights()` time — before any request and before
+    any hipGraph capture — for every 32-token bucket of 65..256 tokens (`prepare`, driven by kernels/linear.py:
+    tune_wide_routes): a few launches of each side, the hand-written kernel taken when it wins by more than 3 %. The table
+    is written next to the checkpoint (`<model_path>/swiftllm_amd_routes.json`; `SWIFTLLM_ROUTE_CACHE` overrides, and a
+    read-only model directory falls back to ~/.cache/swiftllm_amd/) under a lock file, so the first replica of a node
+    measures and every other replica READS the same answer;
+  * `decide()` is a pure lookup: a class nobody measured goes to the library (deterministic), it never times anything,
+    takes no lock and asks the driver for nothing;
   * `SWIFTLLM_ROUTE_TUNE=table` pins the r04 table for every shape (tests that assert WHICH kernel ran), `=off` sends
-    every unmeasured shape to the library.
-Never measured while a stream is capturing (a hipGraph warm-up forward runs eagerly first: worker/model.py)."""
+    every unmeasured shape to the library without measuring."""
 import json
 import os
-import threading
+import time
 
 import torch
 
@@ -24,11 +27,12 @@ MEASURED_DTYPE = torch.bfloat16
 # (N, K) of the Llama-3-8B projections the r04 sweep covered: fused qkv, o_proj, up/gate, down
 MEASURED = {(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336)}
 _TOKEN_BUCKET = 32
+BUCKETS = tuple(range(96, 257, _TOKEN_BUCKET))      # 65..96, ..128, ... ..256 tokens
 _WIN_MARGIN = 1.03
+_LOCK_WAIT_S = 120.0
 
-_lock = threading.Lock()
-_cache = None           # {"<device>|<hip>": {"N,K,dtype,bucket,silu": bool}}
-_dirty = False
+_table = {}             # "N,K,dtype,bucket,silu" -> bool: this process's deployment table
+_device_key_cache = {}
 
 
 def table_wide_wins(m: int, n: int, k: int) -> bool:
@@ -58,44 +62,71 @@ def _mode() -> str:
     return os.environ.get("SWIFTLLM_ROUTE_TUNE", "auto")
 
 
-def _cache_path() -> str:
-    return os.environ.get("SWIFTLLM_ROUTE_CACHE", os.path.join(os.path.expanduser("~"), ".cache", "swiftllm_amd", "routes.json"))
+def _key(n: int, k: int, dtype, bucket: int, silu: bool) -> str:
+    return f"{n},{k},{str(dtype).replace('torch.', '')},{bucket},{int(silu)}"
 
 
-def _device_key(device) -> str:
-    try:
-        name = torch.cuda.get_device_name(device)
-    except Exception:     # noqa: BLE001
-        name = "unknown"
-    return f"{name}|hip {getattr(torch.version, 'hip', None)}|torch {torch.__version__}"
+def bucket_of(m: int) -> int:
+    return -(-m // _TOKEN_BUCKET) * _TOKEN_BUCKET
 
 
-def _load():
-    global _cache
-    if _cache is None:
+def is_measured_class(n: int, k: int, dtype) -> bool:
+    return dtype == MEASURED_DTYPE and (n, k) in MEASURED
+
+
+def decide(m: int, n: int, k: int, dtype: torch.dtype, silu: bool) -> bool:
+    """True = the hand-written kernel. A pure lookup (see the module docstring)."""
+    if _mode() == "table" or is_measured_class(n, k, dtype):
+        return table_wide_silu_wins(m) if silu else table_wide_wins(m, n, k)
+    return bool(_table.get(_key(n, k, dtype, bucket_of(m), silu), False))
+
+
+# ---- the once-per-deployment measurement ------------------------------------------------------------------------------------
+def device_key(device) -> str:
+    key = str(device)
+    if key not in _device_key_cache:
         try:
-            with open(_cache_path(), encoding="utf-8") as f:
-                _cache = json.load(f)
-        except (OSError, ValueError):
-            _cache = {}
-    return _cache
+            name = torch.cuda.get_device_name(device)
+        except Exception:     # noqa: BLE001
+            name = "unknown"
+        _device_key_cache[key] = f"{name}|hip {getattr(torch.version, 'hip', None)}|torch {torch.__version__}"
+    return _device_key_cache[key]
 
 
-def _store():
-    global _dirty
-    path = _cache_path()
+def table_paths(model_path: str):
+    """Where the deployment's table may live, in order of preference."""
+    env = os.environ.get("SWIFTLLM_ROUTE_CACHE")
+    if env:
+        return [env]
+    out = []
+    if model_path and os.path.isdir(model_path):
+        out.append(os.path.join(model_path, "swiftllm_amd_routes.json"))
+    out.append(os.path.join(os.path.expanduser("~"), ".cache", "swiftllm_amd", "routes.json"))
+    return out
+
+
+def _read(path: str) -> dict:
     try:
-        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, encoding="utf-8") as f:
+            data = json.load(f)
+        return data if isinstance(data, dict) else {}
+    except (OSError, ValueError):
+        return {}
+
+
+def _write(path: str, data: dict) -> bool:
+    try:
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
         tmp = f"{path}.{os.getpid()}.tmp"
         with open(tmp, "w", encoding="utf-8") as f:
-            json.dump(_cache, f, indent=0, sort_keys=True)
+            json.dump(data, f, indent=0, sort_keys=True)
         os.replace(tmp, path)
-        _dirty = False
+        return True
     except OSError:
-        pass        # a read-only home: the in-memory table still holds for this process
+        return False
 
 
-def _time_us(fn, iters=8, warm=2) -> float:
+def time_us(fn, iters: int = 8, warm: int = 2) -> float:
     for _ in range(warm):
         fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -107,28 +138,79 @@ def _time_us(fn, iters=8, warm=2) -> float:
     return s.elapsed_time(e) * 1e3 / iters
 
 
-def decide(m: int, n: int, k: int, dtype: torch.dtype, device, silu: bool, run_ours, run_library) -> bool:
-    """True = the hand-written kernel. `run_ours` / `run_library`: zero-argument callables that launch the two candidates on
-    representative operands (called only when this class has to be measured)."""
-    mode = _mode()
-    if mode == "table" or (dtype == MEASURED_DTYPE and (n, k) in MEASURED):
-        return table_wide_silu_wins(m) if silu else table_wide_wins(m, n, k)
-    if mode == "off":
-        return False
-    bucket = -(-m // _TOKEN_BUCKET) * _TOKEN_BUCKET
-    key = f"{n},{k},{str(dtype).replace('torch.', '')},{bucket},{int(silu)}"
-    with _lock:
-        dev = _load().setdefault(_device_key(device), {})
-        if key in dev:
-            return bool(dev[key])
-    if torch.cuda.is_current_stream_capturing():
-        return False        # (cannot time inside a capture; the eager warm-up forward before it has normally decided)
+def prepare(classes, dtype, device, model_path: str, measure) -> dict:
+    """Fill this process's table for `classes` — an iterable of (N, K, silu) — at every token bucket.
+    `measure(n, k, silu, bucket) -> bool` times the two candidates (kernels/linear.py supplies it). Classes the r04 table
+    answers are skipped; answers already in the deployment's file (same device + software key) are READ, not re-measured;
+    what is missing is measured under a lock file so that concurrently starting replicas do it once. Returns
+    {"measured": n, "read": n, "path": file or None}."""
+    stats = {"measured": 0, "read": 0, "path": None}
+    if _mode() in ("table", "off"):
+        return stats
+    want = [(n, k, bool(silu), b) for (n, k, silu) in sorted(set(classes)) if not is_measured_class(n, k, dtype)
+            for b in BUCKETS]
+    if not want:
+        return stats
+    dkey = device_key(device)
+    paths = table_paths(model_path)
+
+    def load_known():
+        for p in paths:
+            dev = _read(p).get(dkey)
+            if isinstance(dev, dict) and all(_key(n, k, dtype, b, s) in dev for n, k, s, b in want):
+                return p, dev
+        return None, None
+    path, dev = load_known()
+    lock = None
+    if dev is None:
+        # one measurer per node: whoever creates the lock file measures, the others wait for the table to appear
+        for p in paths:
+            try:
+                os.makedirs(os.path.dirname(p) or ".", exist_ok=True)
+                fd = os.open(p + ".lock", os.O_CREAT | os.O_EXCL | os.O_WRONLY)
+                os.close(fd)
+                lock, path = p + ".lock", p
+                break
+            except FileExistsError:
+                deadline = time.monotonic() + _LOCK_WAIT_S
+                while time.monotonic() < deadline:
+                    path, dev = load_known()
+                    if dev is not None or not os.path.exists(p + ".lock"):
+                        break
+                    time.sleep(0.2)
+                if dev is not None:
+                    break
+                path = p            # the measurer died or timed out: measure ourselves (same code, same device)
+                break
+            except OSError:
+                continue            # read-only location: try the next one
+    if dev is not None:
+        for n, k, s, b in want:
+            _table[_key(n, k, dtype, b, s)] = bool(dev[_key(n, k, dtype, b, s)])
+        stats.update(read=len(want), path=path)
+        return stats
     try:
-        ours, lib = _time_us(run_ours), _time_us(run_library)
-        wins = bool(ours * _WIN_MARGIN < lib)
-    except Exception:     # noqa: BLE001 — a shape our kernel refuses: the library serves it
-        wins = False
-    with _lock:
-        _load().setdefault(_device_key(device), {})[key] = wins
-        _store()
-    return wins
+        fresh = {}
+        for n, k, s, b in want:
+            try:
+                fresh[_key(n, k, dtype, b, s)] = bool(measure(n, k, s, b))
+            except Exception:     # noqa: BLE001 — a shape our kernel refuses: the library serves it
+                fresh[_key(n, k, dtype, b, s)] = False
+        _table.update(fresh)
+        stats.update(measured=len(want))
+        if path is not None:
+            data = _read(path)
+            data.setdefault(dkey, {}).update(fresh)
+            if _write(path, data):
+                stats["path"] = path
+    finally:
+        if lock is not None:
+            try:
+                os.remove(lock)
+            except OSError:
+                pass
+    return stats
+
+
+def wins(ours_us: float, library_us: float) -> bool:
+    return bool(ours_us * _WIN_MARGIN < library_us)

@@ -118,6 +118,7 @@ class LlamaModel:
                                    self.engine_config.use_dummy, device=self.device,
                                    fuse_qkv=getattr(self.engine_config, "fuse_qkv", False))
         self.repack_decode_weights()
+        self._tune_routes()
         self._init_to_get_rotary()
         self._num_slots = torch.cuda.get_device_properties(self.device).multi_processor_count
         side_stream = torch.cuda.Stream()
@@ -129,6 +130,21 @@ class LlamaModel:
         ]
         self.post_layer = LlamaPostLayer(self.model_config, self.weight)
         self.post_layer.skinny = bool(getattr(self.engine_config, "use_skinny_gemm", False))
+
+    def _tune_routes(self):
+        """Which side serves the 65..256-token decode projections of THIS model on THIS device is decided here, once, before
+        any request (kernels/route_tune.py): the first replica of a node measures the classes the r04 table does not cover
+        and writes the answers next to the checkpoint, every other replica reads them."""
+        ecfg = self.engine_config
+        if not (getattr(ecfg, "use_skinny_gemm", False) and getattr(ecfg, "pack_decode_weights", False)
+                and ecfg.max_batch_size > 64):
+            return
+        from .kernels.linear import tune_wide_routes
+        stats = tune_wide_routes(self.weight.projection_tensors(), [lw.up_gate_proj for lw in self.weight.layers[:1]],
+                                 self.dtype, self.device, ecfg.model_path)
+        if stats.get("measured") or stats.get("read"):
+            print(f"[Model] decode-projection routing: {stats['measured']} (shape, bucket) classes measured, "
+                  f"{stats['read']} read from {stats['path']}", flush=True)
 
     @torch.inference_mode()
     def repack_decode_weights(self):

@@ -7,7 +7,7 @@ The engine keeps the reference's rounding points in both dtypes (no deferred nor
 differ only where the oracle's own top-2 gap is within twice that row's logit distance. Geometries: a small one the engine
 is laid out for (hidden 2048, 16 q / 8 kv heads of 128, FFN 2048, 3 layers) with contexts that cross every split boundary
 (1 ... 70 tokens: most of the 32 context splits empty; ~600 tokens: ragged last split), and the Llama-3-8B width is covered by
-tests/test_gpu_parity_fullwidth.py configs1 / the decisive batch-1 run, which take the engine by default.
+tests/test_gpu_parity_fullwidth.py (its `decode_engine` variant at configs1).
 Every run is wrapped in pytest-timeout: the kernel's waits are bounded (50 ms), a hang here is a bug, not a stall.
 """
 import pytest
@@ -81,8 +81,8 @@ def test_engine_steps_match_the_oracle_and_the_multi_launch_path(tmp_path, dtype
 
     synth.write_model_dir(str(tmp_path), cfg, sd)
     results = {}
-    for name, opts in (("engine_graph", dict()), ("engine_eager", dict(use_hip_graph=False)),
-                       ("multi_launch", dict(tuning=dict(decode_engine=False)))):
+    for name, opts in (("engine_graph", dict(tuning=dict(decode_engine=True))),
+                       ("engine_eager", dict(use_hip_graph=False, tuning=dict(decode_engine=True))), ("multi_launch", dict())):
         model = LlamaModel(EngineConfig(model_path=str(tmp_path), **_kw(dtype, **opts)))
         model.load_weights()
         model.init_kvcache_and_swap(64)
@@ -107,7 +107,7 @@ def test_engine_free_running_generation_equals_teacher_forced_tokens(tmp_path):
     synth.write_model_dir(str(tmp_path), cfg, sd)
     prompt = list(range(40, 75))
     outs = []
-    for opts in (dict(), dict(use_hip_graph=False)):
+    for opts in (dict(tuning=dict(decode_engine=True)), dict(use_hip_graph=False, tuning=dict(decode_engine=True))):
         model = LlamaModel(EngineConfig(model_path=str(tmp_path), **_kw("bfloat16", **opts)))
         model.load_weights()
         model.init_kvcache_and_swap(64)
@@ -134,13 +134,14 @@ def test_a_poisoned_engine_falls_back_to_the_multi_launch_path(tmp_path):
         m.load_weights()
         m.init_kvcache_and_swap(64)
         return m
-    ref = build(tuning=dict(decode_engine=False))
+    ref = build()
     want, _ = _run(ref, prompt, 6)
     del ref
-    model = build()
+    model = build(tuning=dict(decode_engine=True))
     assert model._engine is not None
     first = model.forward([prompt], [0], [])
-    model._engine.ws[1] = 3 | (17 << 8)         # "barrier wait timed out on CU 17"
+    with torch.inference_mode():
+        model._engine.ws[1] = 3 | (17 << 8)     # "barrier wait timed out on CU 17"
     toks = [first]
     n = len(prompt)
     for _ in range(6):

@@ -23,6 +23,7 @@ configs[2] shape: batch 32, ragged ~1k-token prompts, 128 FREE-RUNNING greedy st
 Report: gpurun_out/parity_decisive_<dtype>.json.
 """
 import json
+import os
 import shutil
 
 import pytest
@@ -135,3 +136,18 @@ def test_greedy_ids_bit_exact_for_128_free_running_steps_on_the_decisive_checkpo
     else:
         assert cmp_["max_ulp_of_row"] <= 2.0, report["logits"]
         assert cmp_["max_ulp_of_row"] <= 1.5 * self_ulp + 1.0, report["logits"]
+
+
+@pytest.mark.xfail(strict=False, reason="north_star's 'pre-argmax logits within 1e-3 of the reference Triton path', verbatim, on "
+                   "every one of the 5.3e8 float16 logits of the run above: measured maximum 1.007e-3 (two fp16 ulps across "
+                   "the binade boundary at 0.5) on ONE logit — the priced bar (<= 1.25e-3, <= 1 logit in 1e7 beyond 1e-3) is "
+                   "what the test above asserts; this one keeps the original sentence visible (ADVICE r05)")
+def test_north_star_1e3_logit_bar_verbatim_on_every_float16_logit():
+    """Reads the report the float16 run of the test above has just written (same process, same box)."""
+    path = os.path.join(P.ROOT, "gpurun_out", "parity_decisive_float16.json")
+    if not os.path.exists(path):
+        pytest.skip("the float16 decisive run did not write its report in this session")
+    with open(path, encoding="utf-8") as f:
+        logits = json.load(f)["logits"]
+    assert logits["ours_vs_reference_max_abs"] <= 1e-3, logits["ours_vs_reference_max_abs"]
+    assert logits["logits_beyond_1e3"] == 0

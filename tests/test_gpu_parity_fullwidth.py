@@ -46,7 +46,10 @@ CASES = {
 }
 VARIANTS = (("default", dict()), ("eager_launches", dict(use_hip_graph=False)),
             ("row_major_weights", dict(pack_decode_weights=False)),
-            ("exact_rmsnorm_rounding", dict(tuning=dict(defer_rmsnorm=False))))
+            ("exact_rmsnorm_rounding", dict(tuning=dict(defer_rmsnorm=False))),
+            # batch 1 only: the whole transformer stack of the step as ONE persistent launch (csrc/decode_engine.hip), at the
+            # real Llama-3-8B width, in both dtypes (it keeps the reference's rounding points in float16 too)
+            ("decode_engine", dict(tuning=dict(decode_engine=True))))
 
 
 def _ulp(x: torch.Tensor, dtype) -> torch.Tensor:
@@ -145,7 +148,7 @@ def test_full_width_forward_matches_oracle(tmp_path, case, dtype):
     noise_ulp = max(r["max_ulp_of_row"] for r in report["noise_floor_ref_scores_vs_exact"])
     failures = []
     for name, opts in VARIANTS:
-        if batch > 1 and name in ("eager_launches", "row_major_weights"):
+        if batch > 1 and name in ("eager_launches", "row_major_weights", "decode_engine"):
             continue        # (suite time: both run at batch 1 here; graph == eager bit-equality at batch 32 is tests/test_gpu_model.py's)
         toks, logits = run_hip(opts)
         rows = compare(toks, logits)

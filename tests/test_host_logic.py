@@ -2,6 +2,7 @@
 batch planning, split-K heuristic, the host-mirrored block allocator, configs, weight loading, and
 the "no GPU => loud failure" contract."""
 import itertools
+import json
 import random
 import types
 
@@ -407,38 +408,63 @@ def test_decode_batch_buckets_and_inert_rows():
     assert plan_batch([[1]], [0], [5], 8).real_seqs == 1     # (a plan nobody padded)
 
 
-def test_wide_kernel_routing_measured_table_and_one_off_measurement(tmp_path, monkeypatch):
-    """kernels/route_tune.py: the r04 table answers only for the classes it was measured on (Llama-3-8B widths, bfloat16);
-    anything else is timed once (hand-written kernel taken when > 3 % faster), remembered in memory and on disk, never
-    timed inside a stream capture; SWIFTLLM_ROUTE_TUNE=table / off pin the policy."""
+def test_wide_kernel_routing_is_decided_once_per_deployment(tmp_path, monkeypatch):
+    """kernels/route_tune.py: `decide` is a pure lookup — the r04 table for the classes it was measured on (Llama-3-8B widths,
+    bfloat16), the deployment's table for any other, the library when nobody measured; the measurement happens in `prepare`
+    (load time), is written next to the checkpoint, and a second replica READS it instead of measuring (so two replicas of
+    one deployment route — and therefore round — alike); SWIFTLLM_ROUTE_TUNE=table / off pin the policy."""
     import torch
     from swiftllm_amd.worker.kernels import route_tune as R
-    monkeypatch.setenv("SWIFTLLM_ROUTE_CACHE", str(tmp_path / "routes.json"))
+    monkeypatch.delenv("SWIFTLLM_ROUTE_CACHE", raising=False)
     monkeypatch.delenv("SWIFTLLM_ROUTE_TUNE", raising=False)
-    monkeypatch.setattr(R, "_cache", None)
-    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
-    boom = lambda: (_ for _ in ()).throw(AssertionError("a measured class must not be timed"))   # noqa: E731
-    assert R.decide(128, 4096, 14336, torch.bfloat16, "cpu", False, boom, boom) is True        # down: the table
-    assert R.decide(160, 4096, 4096, torch.bfloat16, "cpu", False, boom, boom) is False        # o_proj at 160: library
-    assert R.decide(192, 28672, 4096, torch.bfloat16, "cpu", True, boom, boom) is False        # SiLU-gate form > 128 tokens
-    times = iter([10.0, 12.0, 10.0, 10.2])      # ours, library | ours, library
+    monkeypatch.setattr(R, "_table", {})
+    monkeypatch.setattr(R, "_device_key_cache", {"cpu": "test-device|hip x|torch y"})
+    bf16, f16 = torch.bfloat16, torch.float16
+    assert R.decide(128, 4096, 14336, bf16, False) is True         # down: the table
+    assert R.decide(160, 4096, 4096, bf16, False) is False         # o_proj at 160: library
+    assert R.decide(192, 28672, 4096, bf16, True) is False         # SiLU-gate form > 128 tokens
+    assert R.decide(100, 5120, 5120, bf16, False) is False         # nobody measured: the library, deterministically
+    assert R.decide(100, 4096, 4096, f16, False) is False          # float16 at a measured (N, K) is not the measured class
+
+    model_dir = tmp_path / "ckpt"
+    model_dir.mkdir()
     calls = []
-    monkeypatch.setattr(R, "_time_us", lambda fn, iters=8, warm=2: (calls.append(fn), next(times))[1])
-    assert R.decide(100, 5120, 5120, torch.bfloat16, "cpu", False, "ours", "lib") is True      # 10 * 1.03 < 12
-    assert R.decide(128, 5120, 5120, torch.bfloat16, "cpu", False, boom, boom) is True         # same 32-token bucket: cached
-    assert R.decide(129, 5120, 5120, torch.bfloat16, "cpu", False, "ours", "lib") is False     # next bucket: a 2 % win is no win
-    assert calls == ["ours", "lib", "ours", "lib"]
-    # float16 at a measured (N, K): not the measured dtype -> timed; a kernel that refuses the shape (here: raises) = library
-    assert R.decide(100, 4096, 4096, torch.float16, "cpu", False, boom, boom) is False
-    monkeypatch.setattr(R, "_cache", None)      # a new process: the file answers
-    assert R.decide(100, 5120, 5120, torch.bfloat16, "cpu", False, boom, boom) is True
-    assert R.decide(130, 5120, 5120, torch.bfloat16, "cpu", False, boom, boom) is False
-    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
-    assert R.decide(100, 6144, 6144, torch.bfloat16, "cpu", False, boom, boom) is False        # capturing: never timed
+
+    def measure(n, k, silu, bucket):
+        calls.append((n, k, silu, bucket))
+        return bucket <= 128 and not silu
+    classes = [(5120, 5120, False), (27648, 5120, True), (4096, 14336, False)]      # the last one: r04 table, never measured
+    st = R.prepare(classes, bf16, "cpu", str(model_dir), measure)
+    assert st["measured"] == 2 * len(R.BUCKETS) and st["read"] == 0
+    assert st["path"] == str(model_dir / "swiftllm_amd_routes.json") and not os.path.exists(st["path"] + ".lock")
+    assert sorted(set(c[:3] for c in calls)) == [(5120, 5120, False), (27648, 5120, True)]
+    assert R.decide(100, 5120, 5120, bf16, False) is True and R.decide(128, 5120, 5120, bf16, False) is True
+    assert R.decide(129, 5120, 5120, bf16, False) is False and R.decide(100, 27648, 5120, bf16, True) is False
+    # a second replica (new process): reads the file, measures nothing, answers alike
+    monkeypatch.setattr(R, "_table", {})
+    boom = lambda *a: (_ for _ in ()).throw(AssertionError("the table must be read, not re-measured"))   # noqa: E731
+    st2 = R.prepare(classes, bf16, "cpu", str(model_dir), boom)
+    assert st2["read"] == 2 * len(R.BUCKETS) and st2["measured"] == 0
+    assert R.decide(100, 5120, 5120, bf16, False) is True and R.decide(160, 5120, 5120, bf16, False) is False
+    # a class the file does not cover yet is measured and merged into the same file; a refusing kernel = library
+    st3 = R.prepare([(7168, 7168, False)], bf16, "cpu", str(model_dir), lambda *a: (_ for _ in ()).throw(RuntimeError("no")))
+    assert st3["measured"] == len(R.BUCKETS) and R.decide(100, 7168, 7168, bf16, False) is False
+    with open(st["path"], encoding="utf-8") as f:
+        on_disk = json.load(f)["test-device|hip x|torch y"]
+    assert len(on_disk) == 3 * len(R.BUCKETS)
+    # a stale lock (the measurer died): wait, then measure ourselves
+    monkeypatch.setattr(R, "_LOCK_WAIT_S", 0.3)
+    other = tmp_path / "ckpt2"
+    other.mkdir()
+    (other / "swiftllm_amd_routes.json.lock").write_text("")
+    st4 = R.prepare([(5120, 5120, False)], bf16, "cpu", str(other), lambda *a: True)
+    assert st4["measured"] == len(R.BUCKETS)
     monkeypatch.setenv("SWIFTLLM_ROUTE_TUNE", "off")
-    assert R.decide(100, 7168, 7168, torch.bfloat16, "cpu", False, boom, boom) is False
+    monkeypatch.setattr(R, "_table", {})
+    assert R.prepare([(9216, 9216, False)], bf16, "cpu", str(model_dir), boom)["measured"] == 0
+    assert R.decide(100, 9216, 9216, bf16, False) is False
     monkeypatch.setenv("SWIFTLLM_ROUTE_TUNE", "table")
-    assert R.decide(100, 4096, 11008, torch.float16, "cpu", False, boom, boom) is True         # K >= 2N by the table
+    assert R.decide(100, 4096, 11008, f16, False) is True          # K >= 2N by the table
 
 
 def test_tiny_batch_projection_policy():
@@ -504,7 +530,9 @@ def test_engine_config_tuning_switches():
     kw = dict(model_path="/x", use_dummy=True, block_size=16, gpu_mem_utilization=0.9, num_cpu_blocks=0,
               max_seqs_in_block_table=8, max_blocks_per_seq=8, max_batch_size=2, max_tokens_in_batch=64)
     ec = EngineConfig(**kw)
-    assert all(getattr(ec, k) is True for k in EngineConfig.TUNING_DEFAULTS)
+    assert all(getattr(ec, k) is v for k, v in EngineConfig.TUNING_DEFAULTS.items())
+    assert all(v is True for k, v in EngineConfig.TUNING_DEFAULTS.items() if k != "decode_engine")   # (opt-in: measured slower)
+    assert EngineConfig(**kw, tuning=dict(decode_engine=True)).decode_engine is True
     ec = EngineConfig(**kw, tuning=dict(defer_rmsnorm=False))
     assert ec.defer_rmsnorm is False and ec.tiny_decode_batches is True
     with pytest.raises(ValueError, match="unknown tuning"):

@@ -838,24 +838,6 @@ def _run(args):
         if args.model == "llama3-8b":
             result["configs1_batch1"] = side_run(args, "llama3-8b", 1, 1024 + GEN // 2, 48, 8,
                                                  "BASELINE.json configs[1]: batch 1 decode-only", model=model)
-            try:        # the same steps through the persistent one-sequence decode engine (opt-in: tuning decode_engine)
-                model.engine_config.decode_engine = True
-                model._build_decode_engine()
-                if model._engine is not None:
-                    model._decode_graphs.clear()
-                    leg = side_run(args, "llama3-8b", 1, 1024 + GEN // 2, 48, 8,
-                                   "BASELINE.json configs[1] through csrc/decode_engine.hip: ONE persistent launch for the 32 "
-                                   "layers of a one-sequence step (opt-in; slower than the 5-6 launches per layer it replaces)",
-                                   model=model)
-                    leg["engine_fallbacks"] = int(model.engine_fallbacks)
-                    result["configs1_batch1_engine"] = leg
-            except Exception as exc:     # noqa: BLE001 — a side measurement must never take the bench line down
-                print(f"[bench] decode-engine side run failed ({type(exc).__name__}: {exc})", file=sys.stderr)
-            finally:
-                model.engine_config.decode_engine = False
-                model._engine = None
-                model._decode_graphs.clear()
-                model._lookahead = None
     del run, model
     torch.cuda.empty_cache()
     if world == 1 and not args.no_extras and args.model == "llama3-8b":
@@ -877,6 +859,20 @@ def _run(args):
                     args, "llama3-8b", nb, S + GEN // 2, 24, 6,
                     f"llama3-8b decode-only, batch {nb} at context ~{S + GEN // 2} (projections: swl_gemm_packed_wide, "
                     f"csrc/gemm_wide.hip)", model=big)
+            try:        # BASELINE configs[1] through the persistent one-sequence decode engine (opt-in: tuning decode_engine), on
+                # this model: its pool leaves room for the engine's third copy of the layer weights (the main model's does not)
+                big.engine_config.decode_engine = True
+                big._build_decode_engine()
+                if big._engine is not None:
+                    big._decode_graphs.clear()
+                    leg = side_run(args, "llama3-8b", 1, 1024 + GEN // 2, 48, 8,
+                                   "BASELINE.json configs[1] through csrc/decode_engine.hip: ONE persistent launch for the 32 "
+                                   "layers of a one-sequence step (opt-in: measured slower than the 5-6 launches per layer "
+                                   "it replaces, see configs1_batch1)", model=big)
+                    leg["engine_fallbacks"] = int(big.engine_fallbacks)
+                    result["configs1_batch1_engine"] = leg
+            except Exception as exc:     # noqa: BLE001 — a side measurement must never take the bench line down
+                print(f"[bench] decode-engine side run failed ({type(exc).__name__}: {exc})", file=sys.stderr)
             del big
             torch.cuda.empty_cache()
         except Exception as exc:     # noqa: BLE001 — a side measurement must never take the bench line down

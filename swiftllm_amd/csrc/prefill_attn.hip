@@ -25,6 +25,8 @@
 //     one XCD so their shared K/V stays in that XCD's L2; long (late) Q blocks are issued first.
 // Numerics as the reference: fp32 scores * (scale*log2e), exp2, P rounded to the storage dtype for
 // the PV product, fp32 accumulators, one rounding at the store (prefill_attn.py:62-71,100).
+#include <stdlib.h>
+
 #include "swl_common.h"
 
 namespace swl {
@@ -314,6 +316,253 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(PrefillParams p) {
     }
 }
 
+
+// ---- r06: LDS-DMA staged variant (head_dim 128) -----------------------------------------------------------------------------
+// Same arithmetic, same fragment order, same bits as prefill_attn_kernel above; what changes is how K/V tiles reach LDS and
+// how many instructions a wave issues per tile. The r02-r05 counters (profiles/r04r_prefill_attn_pmc.md: 9.0 VALU per MFMA,
+// matrix pipe 31-45 % busy) said the loop is short of ISSUE SLOTS, and the ISA showed where they go beside the irreducible
+// softmax: the register-staged K/V (8 global loads + 8 ds_write_b128 + 28 moves + pointer arithmetic per tile) and two
+// barriers per tile. Here:
+//   * K/V tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPRs, no ds_write):
+//     8 DMA instructions per wave per tile, addressed SGPR base + a per-lane 32-bit offset that is the SAME for every tile
+//     (the base advances by one scalar add per tile) — no vector address arithmetic in the loop at all;
+//   * LDS-DMA writes lane-linear images (no row padding possible), so the bank conflicts of the fragment reads are removed
+//     by swizzling on the SOURCE side (the guide's rule 21): the K image holds chunk c of row r at slot c ^ (r & 15)
+//     (ds_read_b128 of 16 rows: 16 distinct slots), the V image holds 64-byte window w of row r at window w ^ (r & 3)
+//     (ds_read_b64_tr_b16 of 4 rows x 64 B: 4 distinct windows); the fragment reads apply the same XOR;
+//   * two LDS buffers, ONE barrier per tile: [wait own DMA of tile t] [barrier] [issue DMA of tile t+1] [compute tile t];
+//     the DMA of the next tile flies under the 32 MFMAs of this one. The DMA and its counted wait are inline asm: hipcc
+//     would put a vmcnt(0) in front of the first LDS read after a DMA it knows about (cdna_hip_programming.md section 5).
+template <typename T>
+__global__ __launch_bounds__(256, 2) void prefill_attn_dma_kernel(PrefillParams p) {
+    constexpr int D = 128;
+    constexpr int KSTEPS = D / 16, DT = D / 32;
+    constexpr int ROWB = D * 2;                 // bytes per K/V row image (256)
+    constexpr int TILEB = kBK * ROWB;           // 16 KiB per K or V tile image
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILEB];      // [buffer][K, V]; the O tiles of the epilogue
+
+    const int G = p.H / p.KVH;
+    const int per_unit = G * p.num_q_blocks;
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int j = id >> 3;
+    const int unit = xcd + 8 * (j / per_unit);
+    if (unit >= p.num_seqs * p.KVH) return;
+    const int inner = j % per_unit;
+    const int g = inner % G;
+    const int qb = p.num_q_blocks - 1 - inner / G; // longest rows first
+    const int seq = unit / p.KVH;
+    const int kvh = unit % p.KVH;
+    const int head = kvh * G + g;
+
+    const int start = p.cu_seqlens[seq];
+    const int len = p.cu_seqlens[seq + 1] - start;
+    const int q0 = qb * kBQ;
+    if (q0 >= len) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31;
+    const int hf = lane >> 5;
+    const int q0w = q0 + wave * 32;
+    const int qrow = q0w + l32;
+    const float c = p.scale_log2e;
+
+    const T *qg = static_cast<const T *>(p.q);
+    vec8_t<T> qf[KSTEPS];
+    {
+        const bool ok = qrow < len;
+        const T *qp = qg + (static_cast<int64_t>(start) + (ok ? qrow : 0)) * p.q_tok_stride +
+                      static_cast<int64_t>(head) * D + hf * 8;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            vec8_t<T> t = load8(qp + kk * 16);
+            if (!ok) t = vec8_t<T>{};
+            qf[kk] = t;
+        }
+    }
+
+    float16_t ot[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) ot[dt] = float16_t{};
+    float m_run = kNegBig;
+    float l_run = 0.f;
+
+    // ---- DMA addressing: this wave stages rows 16 wave + 4 jj + lane/16 (jj = 0..3) of every tile --------------------
+    const int drow = (lane >> 4);                 // + 16 wave + 4 jj
+    const int dslot = lane & 15;
+    const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(
+        (__attribute__((address_space(3))) char *)smem));
+    const int64_t kstride_b = p.k_tok_stride * 2, vstride_b = p.v_tok_stride * 2;
+    unsigned koff[4], voff[4];                    // byte offsets from the tile's base address (row 0 of the tile)
+    auto dma_offsets = [&](int rows_valid) {      // rows_valid: rows of the tile that exist (64 except in the last tile)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int r = 16 * wave + 4 * jj + drow;
+            const int rs = min(r, rows_valid - 1);      // rows past the end: a copy of the last row (masked: key > every q row)
+            koff[jj] = static_cast<unsigned>(rs * kstride_b) + static_cast<unsigned>((dslot ^ (r & 15)) * 16);
+            voff[jj] = static_cast<unsigned>(rs * vstride_b) +
+                       static_cast<unsigned>(((((dslot >> 2) ^ (r & 3)) << 2) | (dslot & 3)) * 16);
+        }
+    };
+    dma_offsets(kBK);
+    const char *kbase = reinterpret_cast<const char *>(static_cast<const T *>(p.k) + static_cast<int64_t>(kvh) * D) +
+                        static_cast<int64_t>(start) * kstride_b;
+    const char *vbase = reinterpret_cast<const char *>(static_cast<const T *>(p.v) + static_cast<int64_t>(kvh) * D) +
+                        static_cast<int64_t>(start) * vstride_b;
+    auto issue_tile = [&](int tile, int buf) {
+        const char *kb = kbase + static_cast<int64_t>(tile) * kBK * kstride_b;     // (wave-uniform: SGPR pair)
+        const char *vb = vbase + static_cast<int64_t>(tile) * kBK * vstride_b;
+        const unsigned ldsk = lds0 + static_cast<unsigned>(buf) * 2 * TILEB + static_cast<unsigned>(wave) * 4096;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(koff[jj]), "s"(kb), "s"(ldsk + jj * 1024) : "memory");
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff[jj]), "s"(vb), "s"(ldsk + TILEB + jj * 1024) : "memory");
+        }
+    };
+
+    const int kv_end = min(len, q0 + kBQ);
+    const int ntiles = (kv_end + kBK - 1) / kBK;
+    const int last_rows = kv_end - (ntiles - 1) * kBK > 0 ? min(kBK, len - (ntiles - 1) * kBK) : kBK;
+
+    // ---- fragment read offsets (bytes, within a buffer) ------------------------------------------------------------------
+    // K: row l32 (+ 32 t), chunk 2 kk + hf at slot (2 kk + hf) ^ (row & 15)
+    unsigned kfo[KSTEPS];
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) kfo[kk] = static_cast<unsigned>(l32 * ROWB + (((2 * kk + hf) ^ (l32 & 15)) * 16));
+    // V (transpose read): row 4 hf + i16/4 (+ 8, + 16 ks, + 32 t), 8 bytes at column 32 dt + 16 ((lane >> 4) & 1) + 4 (i16 & 3)
+    // = window dt, byte 32 ((lane >> 4) & 1) + 8 (i16 & 3) inside it; window stored at dt ^ (row & 3), row & 3 = (i16 >> 2) & 3
+    const int i16 = lane & 15;
+    unsigned vfo[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+        vfo[dt] = static_cast<unsigned>(TILEB + (4 * hf + (i16 >> 2)) * ROWB + ((dt ^ ((i16 >> 2) & 3)) * 64) +
+                                        32 * ((lane >> 4) & 1) + 8 * (i16 & 3));
+
+    if (ntiles == 1 && last_rows < kBK) dma_offsets(last_rows);
+    issue_tile(0, 0);
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int key0 = tile * kBK;
+        const int buf = tile & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of tile `tile` have landed
+        __builtin_amdgcn_s_barrier();                        // ... everyone's; and everyone is done reading the other buffer
+        if (tile + 1 < ntiles) {
+            if (tile + 2 == ntiles && last_rows < kBK) dma_offsets(last_rows);
+            issue_tile(tile + 1, buf ^ 1);                   // flies under the MFMAs below
+        }
+        if (key0 > q0w + 31) continue; // whole tile above this wave's diagonal
+        const char *bufp = smem + buf * 2 * TILEB;
+
+        float16_t st[2];
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            st[t] = float16_t{};
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                const vec8_t<T> kf = *reinterpret_cast<const vec8_t<T> *>(bufp + kfo[kk] + t * 32 * ROWB);
+                st[t] = mfma32(kf, qf[kk], st[t]);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        mfma_results_tie(st[0]);
+        mfma_results_ready<8>(st[1]);
+        if (key0 + kBK - 1 > q0w) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                    if (key > qrow) st[t][r] = kNegBig;
+                }
+        }
+        float mx = st[0][0];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx * c);
+        const float alpha = fast_exp2(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = fast_exp2(fmaf(st[t][r], c, -m_new));
+                st[t][r] = pv;
+                psum += pv;
+            }
+        l_run = fmaf(l_run, alpha, psum);
+        if (!__all(alpha == 1.0f)) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+        }
+
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                vec8_t<T> pb;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) pb[jj] = to_t<T>(st[t][8 * ks + jj]);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const T *vp = reinterpret_cast<const T *>(bufp + vfo[dt] + (t * 32 + 16 * ks) * ROWB);
+                    const short4_t lo = lds_tr_read(vp);
+                    const short4_t hi = lds_tr_read(vp + 8 * D);
+                    typedef short short8_t __attribute__((ext_vector_type(8)));
+                    const short8_t both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    const vec8_t<T> vf = __builtin_bit_cast(vec8_t<T>, both);
+                    ot[dt] = mfma32(vf, pb, ot[dt]);
+                }
+            }
+        __builtin_amdgcn_s_setprio(0);
+    }
+
+    // ---- epilogue: as prefill_attn_kernel (whole-row stores through LDS) ------------------------------------------------------
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) mfma_results_tie(ot[dt]);
+    mfma_results_ready<8>(ot[DT - 1]);
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    constexpr int ORS = D + 8;
+    static_assert(4 * 32 * ORS * 2 <= 4 * TILEB, "the four waves' O tiles must fit the K/V buffers");
+    __syncthreads();                                 // every wave is done with the last K/V tile (no DMA is in flight)
+    T *ow = reinterpret_cast<T *>(smem) + wave * 32 * ORS;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            typedef T vec4 __attribute__((ext_vector_type(4)));
+            vec4 ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[e] = to_t<T>(ot[dt][4 * r4 + e] * inv);
+            *reinterpret_cast<vec4 *>(ow + l32 * ORS + dt * 32 + 8 * r4 + 4 * hf) = ov;
+        }
+    constexpr int CPR = D / 8, RPI = 64 / CPR;
+    T *obase = static_cast<T *>(p.o) + static_cast<int64_t>(start) * p.o_tok_stride + static_cast<int64_t>(head) * D;
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+        const int row = i * RPI + lane / CPR, ch = lane % CPR;
+        const vec8_t<T> v = *reinterpret_cast<const vec8_t<T> *>(ow + row * ORS + ch * 8);
+        if (q0w + row < len)
+            store8(obase + static_cast<int64_t>(q0w + row) * p.o_tok_stride + ch * 8, v);
+    }
+}
+
 } // namespace swl
 
 extern "C" int swl_prefill_attn_varlen(void *o, const void *q, const void *k, const void *v,
@@ -354,8 +603,13 @@ extern "C" int swl_prefill_attn_varlen(void *o, const void *q, const void *k, co
     if (nblocks > 0x7fffffffLL) return SWL_ERR_UNSUPPORTED;
     const dim3 grid(static_cast<unsigned>(nblocks));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // A/B switch for measurements: SWL_PREFILL_ATTN=v1 runs the register-staged kernel at head_dim 128 as well
+    static const bool use_v1 = [] { const char *e = getenv("SWL_PREFILL_ATTN"); return e && e[0] == 'v' && e[1] == '1'; }();
+    const bool fits32 = static_cast<int64_t>(swl::kBK) * (k_tok_stride > v_tok_stride ? k_tok_stride : v_tok_stride) * 2 + 4096 < (1ll << 32);
     SWL_DISPATCH_DTYPE(dtype, T, {
-        if (head_dim == 128)
+        if (head_dim == 128 && !use_v1 && fits32)
+            hipLaunchKernelGGL((swl::prefill_attn_dma_kernel<T>), grid, dim3(256), 0, s, p);
+        else if (head_dim == 128)
             hipLaunchKernelGGL((swl::prefill_attn_kernel<T, 128>), grid, dim3(256), 0, s, p);
         else if (head_dim == 64)
             hipLaunchKernelGGL((swl::prefill_attn_kernel<T, 64>), grid, dim3(256), 0, s, p);

@@ -1,7 +1,7 @@
 """Kernel routing is decided ONCE per deployment and identically for every replica.
 
 Two replica processes start AT THE SAME TIME on the one GPU of the box against one checkpoint whose projection widths are in
-no measured table (hidden 5120 = Llama-2-13B's width: 40 q / 8 kv heads of 128, FFN 13824, one layer): `load_weights()` of
+no measured table (hidden 5120 = Llama-2-13B's width: 40 q / 10 kv heads of 128, FFN 13824, one layer): `load_weights()` of
 the first one to take the lock file measures every (shape, 32-token bucket) class of 65..256 tokens and writes
 `<model_path>/swiftllm_amd_routes.json`; the other one waits and READS it. Both then decode the same batch of 96 sequences:
 the logits must be BIT-identical (the two candidate kernels sum K in different orders, so replicas that routed differently
@@ -45,7 +45,7 @@ print(json.dumps(dict(sha=hashlib.sha256(lg.numpy().tobytes()).hexdigest(), toke
 
 
 def test_two_replicas_of_one_deployment_route_alike_and_return_identical_logits(tmp_path):
-    cfg = synth.make_config(num_hidden_layers=1, hidden_size=5120, num_attention_heads=40, num_key_value_heads=8,
+    cfg = synth.make_config(num_hidden_layers=1, hidden_size=5120, num_attention_heads=40, num_key_value_heads=10,
                             intermediate_size=13824, vocab_size=512, max_position_embeddings=512)
     import torch
     sd = synth.make_state_dict(cfg, seed=21, dtype=torch.bfloat16)

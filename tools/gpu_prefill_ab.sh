@@ -1,13 +1,16 @@
 #!/bin/bash
-# A/B of a prefill-attention variant library (tools/probe/prefill_attn_v*.hip built with `build.py --tag <t> --swap ...`)
-# against the product kernel: micro at three shapes + the kernel's parity tests on the variant.
+# tools/gpu_prefill_ab.sh — prefill attention: parity tests on the shipped kernel, then the LDS-DMA kernel (default at head_dim 128)
+# against the register-staged one (SWL_PREFILL_ATTN=v1), interleaved rounds in one session.
 mkdir -p gpurun_out; export TMPDIR=/tmp
-for lib in "" ${VARIANTS:-pa2}; do
-  if [ -n "$lib" ]; then export SWIFTLLM_HIP_LIB=$PWD/swiftllm_amd/csrc/libswiftllm_hip_${lib}.so; else unset SWIFTLLM_HIP_LIB; fi
-  for sh in c3 mid c4 ragged; do
-    echo "lib=${lib:-product} $(python tools/prefill_attn_micro.py --shape $sh 2>/dev/null | tail -1)"
+timeout 900 python -m pytest tests/test_gpu_kernels.py -q -x -k "prefill" --timeout=600 > gpurun_out/prefill_tests.log 2>&1; echo "pytest rc=$?"; tail -5 gpurun_out/prefill_tests.log
+: > gpurun_out/prefill_attn_ab.jsonl
+for round in 1 2 3; do
+  for shape in c3 mid c4 ragged; do
+    for v in dma v1; do
+      if [ $v = v1 ]; then export SWL_PREFILL_ATTN=v1; else unset SWL_PREFILL_ATTN; fi
+      timeout 300 python tools/prefill_attn_micro.py --shape $shape --iters 20 | sed "s/^{/{\"variant\": \"$v\", \"round\": $round, /" >> gpurun_out/prefill_attn_ab.jsonl
+    done
   done
-done | tee gpurun_out/prefill_ab.jsonl
-for lib in ${VARIANTS:-pa2}; do
-  SWIFTLLM_HIP_LIB=$PWD/swiftllm_amd/csrc/libswiftllm_hip_${lib}.so timeout 600 python -m pytest tests/test_gpu_kernels.py -q -k "prefill" 2>&1 | tail -2
 done
+unset SWL_PREFILL_ATTN
+cat gpurun_out/prefill_attn_ab.jsonl

@@ -662,28 +662,33 @@ def mixed_step_run(model, cfg, batch, prompt_len, context, n_prefill=4, reps=5):
                 tokens_per_s=round((n_prefill * prompt_len + len(dec_ids)) / ms["mixed"] * 1e3, 1), reps=reps)
 
 
-def side_run_fresh_process(args, label):
-    """configs[3] as its own `bench.py --model llama2-7b --batch 4 --prompt-len 16384 --gen-len 64 --skip-prefill` run in
-    a child process (this process has released its model): the 47 GB a step streams then sit in a freshly mapped
-    address space — measured as the last side run of THIS process, after a 30 GB model was built and freed, the same
-    code ran 15 % slower (9.7 vs 8.4 ms/step, profiles/r02q). Returns None when the child fails (the caller falls back
-    to the in-process run)."""
+def side_run_fresh_process(args, label, model_name="llama2-7b", batch=4, prompt_len=16384, gen_len=64, steps=24, warmup=4,
+                           extra=(), timeout=420):
+    """A side measurement as its own `bench.py --model M --batch B ... --skip-prefill --no-extras` run in a child process
+    (this process has released its model). Two users: configs[3] — the 47 GB a step streams then sit in a freshly mapped
+    address space (measured as the last side run of THIS process, after a 30 GB model was built and freed, the same code
+    ran 15 % slower: 9.7 vs 8.4 ms/step, profiles/r02q_*) — and the persistent decode engine, whose third copy of the
+    layer weights wants its own pool sizing and whose failure must not reach the allocator / capture state of this
+    process (round-6 driver-form run: an engine built on a model that had already replayed graphs tripped a
+    HIPCachingAllocator assert and took the float16 and long-prompt legs down with it). Returns None when the child fails."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--model", "llama2-7b", "--batch", "4", "--prompt-len", "16384",
-           "--gen-len", "64", "--skip-prefill", "--steps", "24", "--warmup", "4", "--no-extras", "--no-cpu-baseline",
-           "--dtype", args.dtype]
+    cmd = [sys.executable, os.path.abspath(__file__), "--model", model_name, "--batch", str(batch), "--prompt-len",
+           str(prompt_len), "--gen-len", str(gen_len), "--skip-prefill", "--steps", str(steps), "--warmup", str(warmup),
+           "--no-extras", "--no-cpu-baseline", "--dtype", args.dtype, *extra]
     if args.no_hip_graph:
         cmd.append("--no-hip-graph")
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, check=True)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, check=True)
         d = json.loads(r.stdout.strip().splitlines()[-1])
         first, last = d["config"]["timed_contexts"]
-        return dict(workload=label, model="llama2-7b", batch=4, context_first=first, context_last=last, steps=d["steps"],
+        return dict(workload=label, model=model_name, batch=batch, context_first=first, context_last=last, steps=d["steps"],
                     warmup=d["warmup"], ms_per_step=d["ms_per_step"], decode_tok_s=d["value"],
                     hip_graph=bool(d["config"].get("hip_graph")), step_roofline=d["step_roofline"],
-                    how="child process: " + " ".join(cmd[1:]))
+                    how="child process: " + " ".join(cmd[1:]),
+                    **{k: d["config"][k] for k in ("decode_engine_active", "decode_engine_fallbacks") if k in d["config"]})
     except Exception as e:     # noqa: BLE001 — a side measurement must never take the bench line down
-        print(f"[bench] configs[3] child run failed ({type(e).__name__}: {e}); measuring in-process", file=sys.stderr)
+        tail = getattr(e, "stderr", "") or ""
+        print(f"[bench] child run failed ({label[:40]}...: {type(e).__name__}: {e}) {tail[-400:]}", file=sys.stderr)
         return None
 
 
@@ -761,6 +766,9 @@ def _run(args):
     pool = pool_report(model)
     units, max_s = dp.reduce_job(B * K, local_s)
     graphs = len(getattr(model, "_decode_graphs", {}))
+    engine_state = ({"decode_engine_active": getattr(model, "_engine", None) is not None,
+                     "decode_engine_fallbacks": int(getattr(model, "engine_fallbacks", 0))}
+                    if getattr(args, "decode_engine", False) else {})
 
     if rank != 0:
         return None
@@ -781,7 +789,7 @@ def _run(args):
                    "parallelism": f"request-sharded dp{world} (independent replicas, no collective)",
                    "hip_graph": not args.no_hip_graph, "fuse_qkv": args.fuse_qkv,
                    "skinny_gemm": args.skinny_gemm, "packed_decode_weights": getattr(args, "packed_weights", True),
-                   **pool, "decode_graphs_captured": graphs,
+                   **pool, "decode_graphs_captured": graphs, **engine_state,
                    "cpu_affinity_cores": len(pinned) if pinned else len(os.sched_getaffinity(0)),
                    "cpu_affinity": dict(dp.last_affinity) if world > 1 else dict(
                        cores=len(os.sched_getaffinity(0)), how="single rank on this host: not pinned, all allowed cores")},
@@ -859,24 +867,20 @@ def _run(args):
                     args, "llama3-8b", nb, S + GEN // 2, 24, 6,
                     f"llama3-8b decode-only, batch {nb} at context ~{S + GEN // 2} (projections: swl_gemm_packed_wide, "
                     f"csrc/gemm_wide.hip)", model=big)
-            try:        # BASELINE configs[1] through the persistent one-sequence decode engine (opt-in: tuning decode_engine), on
-                # this model: its pool leaves room for the engine's third copy of the layer weights (the main model's does not)
-                big.engine_config.decode_engine = True
-                big._build_decode_engine()
-                if big._engine is not None:
-                    big._decode_graphs.clear()
-                    leg = side_run(args, "llama3-8b", 1, 1024 + GEN // 2, 48, 8,
-                                   "BASELINE.json configs[1] through csrc/decode_engine.hip: ONE persistent launch for the 32 "
-                                   "layers of a one-sequence step (opt-in: measured slower than the 5-6 launches per layer "
-                                   "it replaces, see configs1_batch1)", model=big)
-                    leg["engine_fallbacks"] = int(big.engine_fallbacks)
-                    result["configs1_batch1_engine"] = leg
-            except Exception as exc:     # noqa: BLE001 — a side measurement must never take the bench line down
-                print(f"[bench] decode-engine side run failed ({type(exc).__name__}: {exc})", file=sys.stderr)
             del big
             torch.cuda.empty_cache()
         except Exception as exc:     # noqa: BLE001 — a side measurement must never take the bench line down
             print(f"[bench] large-batch side runs failed ({type(exc).__name__}: {exc})", file=sys.stderr)
+    if world == 1 and not args.no_extras and args.model == "llama3-8b":
+        # BASELINE configs[1] through the persistent one-sequence decode engine (opt-in: tuning decode_engine), in its own
+        # process: the pool is sized around the engine's third copy of the layer weights there
+        leg = side_run_fresh_process(
+            args, "BASELINE.json configs[1] through csrc/decode_engine.hip: ONE persistent launch for the 32 layers of a "
+                  "one-sequence step (opt-in: measured slower than the 5-6 launches per layer it replaces, see configs1_batch1)",
+            model_name="llama3-8b", batch=1, prompt_len=1024, gen_len=GEN, steps=48, warmup=8,
+            extra=("--decode-engine", "--kv-blocks", "8192", "--kv-placement", "bottom"))
+        if leg is not None:
+            result["configs1_batch1_engine"] = leg
     if world == 1 and not args.no_extras and args.model == "llama3-8b":
         try:        # the reference's own precision on the same batch and contexts (its Triton path is float16-only)
             if args.dtype != "float16":

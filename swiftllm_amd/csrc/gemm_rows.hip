@@ -25,6 +25,14 @@
 //     the CU's own rate; longer K (down_proj: 14 chunks) refills a 4-deep ring of 4-step chunks behind exact counted waits;
 //   * the 8 waves' 16 x 32 fp32 tiles meet in LDS (20 KiB), are added in wave order (= K order: deterministic), and the
 //     512 threads finish one (token, column) each: residual += round(acc), the consumer launch's rounding points.
+// r06b — x through a wave-private LDS tile (XLDS = true: from 9 tokens on). The fragment-shaped x loads above are 16 rows x 64 B
+// per instruction: sixteen HALF cache lines per KiB delivered, and at 32 tokens x is 2/3 of what a CU pulls through its L1
+// (the r05 "57 GB/s per CU, hit or miss" was measured through exactly that pattern). Here a wave requests its x chunk
+// (32 tokens x 128 k) as FULL lines — lane -> (token 4i + lane/16, 16-byte piece lane%16): 4 rows x 256 contiguous bytes per
+// instruction, the same register budget (8 loads per chunk at two token blocks) — and turns it into B fragments through an
+// 8 KiB LDS tile of its own: ds_write_b128 at piece ^ (token & 15), ds_read_b128 of lane (r, kq) at (4j + kq) ^ r —
+// conflict-free for the 8-lane write groups and for the irregular 16-lane groups of the b128 read.
+// One wave's LDS operations execute in order: no barrier in the stream. Same MFMAs in the same order: the same bits.
 // No slabs, no second launch, no atomics, no cross-workgroup hand-off. (r05 also built an epilogue that wrote
 // round(residual * w_norm) and one sum-of-squares partial per tile, with a SiLU-gate GEMM that added the 256 partials from
 // LDS-DMA'd copies: correct, +2 us on the up/gate kernel, removed — last revision that has it: ca4e9a9, numbers in
@@ -56,9 +64,12 @@ struct RowsArgs {
 
 // NCH > 0: the chunk count per wave is a compile-time constant <= kRowsRing — every load is issued up front, straight-line
 // code with exact counted waits. NCH == 0: run-time chunk count, the ring refilled behind guards.
-template <typename T, int NCH, int MB>
+template <typename T, int NCH, int MB, bool XLDS>
 __global__ __launch_bounds__(kRowsWaves * 64, 2) void gemm_rows_kernel(RowsArgs a) {
     __shared__ __attribute__((aligned(16))) float red[kRowsWaves][32 * kRowsRedPitch];
+    constexpr int XCK = 32 * kRowsCh;          // k per chunk (128): one 256-byte run per token
+    constexpr int NXL = XLDS ? 4 * MB : kRowsCh * MB;   // x loads per chunk and lane (XLDS: 4 token rows each)
+    __shared__ __attribute__((aligned(16))) T xt[XLDS ? kRowsWaves : 1][XLDS ? 16 * MB * XCK : 8];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int M = a.M, N = a.N, K = a.K;
@@ -81,28 +92,57 @@ __global__ __launch_bounds__(kRowsWaves * 64, 2) void gemm_rows_kernel(RowsArgs 
     const T *wsrc = static_cast<const T *>(a.wp) +
                     (static_cast<int64_t>(tile16 >> 1) * (K / 16) + 2 * s0 + (kq >> 1)) * 512 +
                     (16 * (tile16 & 1) + r + 32 * (kq & 1)) * 8;
-    const T *xsrc[MB];
+    // fragment form: xsrc[mb] = row r + 16 mb at k = 8 kq; XLDS: xsrc[i] = row 4 i + lane/16 at piece lane%16 of the chunk
+    const T *xsrc[XLDS ? NXL : MB];
+    int xw_off[XLDS ? NXL : 1];                  // XLDS: where this lane's piece of load i goes in the tile (elements)
+    int xr_off[XLDS ? kRowsCh : 1];              // XLDS: B fragment of k-step j of the chunk, token block 0 (elements)
+    if constexpr (XLDS) {
+        const int tsub = lane >> 4, pc = lane & 15;
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-        xsrc[mb] = static_cast<const T *>(a.x) + static_cast<int64_t>(min(r + 16 * mb, M - 1)) * a.x_stride + 32 * s0 + 8 * kq;
+        for (int i = 0; i < NXL; ++i) {
+            const int tk = 4 * i + tsub;
+            xsrc[i] = static_cast<const T *>(a.x) + static_cast<int64_t>(min(tk, M - 1)) * a.x_stride + 32 * s0 + 8 * pc;
+            xw_off[i] = tk * XCK + ((pc ^ (tk & 15)) << 3);
+        }
+#pragma unroll
+        for (int j = 0; j < kRowsCh; ++j) xr_off[j] = r * XCK + (((4 * j + kq) ^ r) << 3);
+    } else {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+            xsrc[mb] = static_cast<const T *>(a.x) + static_cast<int64_t>(min(r + 16 * mb, M - 1)) * a.x_stride + 32 * s0 + 8 * kq;
+    }
+    T *xtw = &xt[XLDS ? wave : 0][0];
 
-    vec8_t<T> wr[kRowsRing][kRowsCh], xr[kRowsRing][kRowsCh][MB];
+    vec8_t<T> wr[kRowsRing][kRowsCh], xr[kRowsRing][NXL];
     float4_t acc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[mb] = float4_t{0.f, 0.f, 0.f, 0.f};
 #define SWL_ROWS_ISSUE(slot, c)                                                                         \
     {                                                                                                   \
+        if constexpr (XLDS) {   /* x first: the chunk's x is what the LDS pass waits for (loads return in order) */ \
+            _Pragma("unroll") for (int i_ = 0; i_ < NXL; ++i_) xr[slot][i_] = load8(xsrc[i_] + (c) * XCK); \
+        }                                                                                               \
         _Pragma("unroll") for (int j_ = 0; j_ < kRowsCh; ++j_) {                                        \
             const int s_ = (c) * kRowsCh + j_;                                                          \
             wr[slot][j_] = load8_nt(wsrc + static_cast<int64_t>(s_) * 1024);                            \
-            _Pragma("unroll") for (int mb_ = 0; mb_ < MB; ++mb_) xr[slot][j_][mb_] = load8(xsrc[mb_] + s_ * 32); \
+            if constexpr (!XLDS) {                                                                      \
+                _Pragma("unroll") for (int mb_ = 0; mb_ < MB; ++mb_) xr[slot][j_ * MB + mb_] = load8(xsrc[mb_] + s_ * 32); \
+            }                                                                                           \
         }                                                                                               \
     }
 #define SWL_ROWS_PROCESS(slot)                                                                          \
     {                                                                                                   \
+        if constexpr (XLDS) {                                                                           \
+            _Pragma("unroll") for (int i_ = 0; i_ < NXL; ++i_)                                          \
+                *reinterpret_cast<vec8_t<T> *>(xtw + xw_off[i_]) = xr[slot][i_];                        \
+        }                                                                                               \
         _Pragma("unroll") for (int j_ = 0; j_ < kRowsCh; ++j_)                                          \
-            _Pragma("unroll") for (int mb_ = 0; mb_ < MB; ++mb_)                                        \
-                acc[mb_] = rows_mfma(wr[slot][j_], xr[slot][j_][mb_], acc[mb_]);                        \
+            _Pragma("unroll") for (int mb_ = 0; mb_ < MB; ++mb_) {                                      \
+                vec8_t<T> b_;                                                                           \
+                if constexpr (XLDS) b_ = *reinterpret_cast<const vec8_t<T> *>(xtw + xr_off[j_] + mb_ * 16 * XCK); \
+                else b_ = xr[slot][j_ * MB + mb_];                                                      \
+                acc[mb_] = rows_mfma(wr[slot][j_], b_, acc[mb_]);                                       \
+            }                                                                                           \
     }
     if constexpr (NCH > 0) {
         // straight-line schedule, exact counted waits: the first min(NCH, ring) chunks are requested up front (K = 4096:
@@ -159,16 +199,24 @@ static bool rows_shape_ok(int M, int N, int K) {
     return M > 0 && M <= 32 && N > 0 && N % 32 == 0 && K > 0 && K % (32 * kRowsWaves * kRowsCh) == 0;
 }
 
-template <typename T, int MB>
+template <typename T, int MB, bool XLDS>
 static int launch_rows(const RowsArgs &a, hipStream_t stream) {
     const dim3 grid(a.N / kRowsTile), block(kRowsWaves * 64);
     const int nch = a.K / (32 * kRowsWaves * kRowsCh);
     // K = 4096 (Llama-3-8B / Llama-2-7B hidden): 4 chunks, all in flight; 14336 (Llama-3-8B FFN): 14; 8192: 8
-    if (nch == 4) hipLaunchKernelGGL((gemm_rows_kernel<T, 4, MB>), grid, block, 0, stream, a);
-    else if (nch == 14) hipLaunchKernelGGL((gemm_rows_kernel<T, 14, MB>), grid, block, 0, stream, a);
-    else if (nch == 8) hipLaunchKernelGGL((gemm_rows_kernel<T, 8, MB>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((gemm_rows_kernel<T, 0, MB>), grid, block, 0, stream, a);
+    if (nch == 4) hipLaunchKernelGGL((gemm_rows_kernel<T, 4, MB, XLDS>), grid, block, 0, stream, a);
+    else if (nch == 14) hipLaunchKernelGGL((gemm_rows_kernel<T, 14, MB, XLDS>), grid, block, 0, stream, a);
+    else if (nch == 8) hipLaunchKernelGGL((gemm_rows_kernel<T, 8, MB, XLDS>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((gemm_rows_kernel<T, 0, MB, XLDS>), grid, block, 0, stream, a);
     return check_launch();
+}
+
+// x through LDS pays from 9 tokens on (graph-timed on MI355X, profiles/r06b_rows_kernel_us.jsonl: o_proj 32 tokens 11.7 ->
+// 10.5 us, down_proj 16 / 32 tokens 25.0 -> 23.8 / 34.4 -> 28.4; at one token the LDS hop costs o_proj 0.45 us, at 16 the
+// two forms tie). A/B switch for measurements: SWL_ROWS_X=frag / lds forces one form for every M (same bits either way).
+static bool rows_x_through_lds(int M) {
+    static const int forced = [] { const char *e = getenv("SWL_ROWS_X"); return !e ? 0 : e[0] == 'f' ? 1 : e[0] == 'l' ? 2 : 0; }();
+    return forced ? forced == 2 : M > 8;
 }
 
 } // namespace swl
@@ -187,7 +235,9 @@ extern "C" int swl_gemm_rows_add(void *residual, const void *x, const void *w_pa
     a.x = x; a.wp = w_packed; a.residual = residual;
     a.M = M; a.N = N; a.K = K; a.x_stride = x_row_stride;
     SWL_DISPATCH_DTYPE(dtype, T, {
-        if (M <= 16) return swl::launch_rows<T, 1>(a, static_cast<hipStream_t>(stream));
-        return swl::launch_rows<T, 2>(a, static_cast<hipStream_t>(stream));
+        const hipStream_t s = static_cast<hipStream_t>(stream);
+        if (swl::rows_x_through_lds(M))
+            return M <= 16 ? swl::launch_rows<T, 1, true>(a, s) : swl::launch_rows<T, 2, true>(a, s);
+        return M <= 16 ? swl::launch_rows<T, 1, false>(a, s) : swl::launch_rows<T, 2, false>(a, s);
     });
 }

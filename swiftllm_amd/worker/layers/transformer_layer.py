@@ -51,11 +51,13 @@ from ..kernels.silu_and_mul import silu_and_mul_inplace
 
 
 class LlamaTransformerLayer:
-    # Where the row-owned projections win on MI355X (tools/gemm_rows_micro.py --layer, profiles/r05c_*): every workgroup
-    # of such a projection pulls ALL of x through its own L1 at ~55 GB/s, so the win shrinks with the batch — o_proj (x =
-    # M x 8 KiB) ties the split-K pair at 32 sequences, down_proj (x = M x 28 KiB) at 16.
+    # Where the row-owned projections win on MI355X (tools/gemm_rows_micro.py --layer, tools/rows_kernel_us.py): every
+    # workgroup of such a projection pulls ALL of x through its own L1, so the win shrinks with the batch. With x staged as
+    # full lines through LDS (r06b, csrc/gemm_rows.hip) o_proj (x = M x 8 KiB) beats the split-K pair at 32 sequences by
+    # ~4 us (10.5 vs 9.6 + 5), down_proj (x = M x 28 KiB) wins by ~3 us at 16 (23.8 vs 20.5 + 5; layer chain 83.1 vs 86.3),
+    # ties at 24 and loses at 32 (28.4 vs 21.4 + 5) — profiles/r06b_rows_ab.jsonl, r06b_rows_kernel_us.jsonl. (r05: 8.)
     ROWS_O_MAX_M = 32
-    ROWS_DOWN_MAX_M = 8
+    ROWS_DOWN_MAX_M = 16
 
     def __init__(self, model_config, engine_config, weight, decoding_piggyback_stream, layer_id: int):
         self.model_config = model_config

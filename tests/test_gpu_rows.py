@@ -119,13 +119,14 @@ def _engine_config(path, **kw):
     return EngineConfig(**base)
 
 
-@pytest.mark.parametrize("batch", [1, 2, 5, 8, 9, 32])
+@pytest.mark.parametrize("batch", [1, 2, 8, 9, 16, 17, 32])
 def test_rows_decode_path_equals_the_consumer_path(tmp_path, batch):
     """The rows_decode switch at Llama-3-8B layer geometry (3 layers): the engine with row-owned o_proj / down_proj + norm on
     the fly against the same engine with the split-K + consumer launches (and the <= 2-sequence tiny path), teacher-forced over
     6 decode steps, with hipGraph replay and with eager launches: logits within the storage dtype's rounding (the arithmetic
     differences are the fp32 summation order of the sums of squares and of the row-owned products), greedy ids identical
-    except on near-ties. Batches on both sides of ROWS_DOWN_MAX_M (8) and at ROWS_O_MAX_M (32)."""
+    except on near-ties. Batches on both sides of the x-through-LDS switch of csrc/gemm_rows.hip (8 | 9), on both sides of
+    ROWS_DOWN_MAX_M (16 | 17) and at ROWS_O_MAX_M (32)."""
     cfg = synth.make_config(num_hidden_layers=3, hidden_size=4096, num_attention_heads=32, num_key_value_heads=8,
                             intermediate_size=14336, vocab_size=4096, max_position_embeddings=2048, rope_theta=500000.0)
     dtype = "bfloat16"

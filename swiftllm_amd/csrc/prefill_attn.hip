@@ -371,17 +371,6 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_dma_kernel(PrefillParams 
 
     const T *qg = static_cast<const T *>(p.q);
     vec8_t<T> qf[KSTEPS];
-    {
-        const bool ok = qrow < len;
-        const T *qp = qg + (static_cast<int64_t>(start) + (ok ? qrow : 0)) * p.q_tok_stride +
-                      static_cast<int64_t>(head) * D + hf * 8;
-#pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) {
-            vec8_t<T> t = load8(qp + kk * 16);
-            if (!ok) t = vec8_t<T>{};
-            qf[kk] = t;
-        }
-    }
 
     float16_t ot[DT];
 #pragma unroll
@@ -449,6 +438,35 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_dma_kernel(PrefillParams 
 
     if (ntiles == 1 && last_rows < kBK) dma_offsets(last_rows);
     issue_tile(0, 0);
+    // ---- Q^T fragments (r06b): full-line loads through LDS instead of fragment-shaped ones ----------------------------------
+    // The B fragment of lane (row l32, half hf) is 16 bytes of a 256-byte row: loaded directly, one instruction gathers 32
+    // rows x 32 B (quarter lines: the slowest load shape on this part, tools/probe/l2_fill_probe.hip). Here a wave requests
+    // its 32 rows as 8 x (4 rows x 256 B), parks them in its 8 KiB of the SECOND K/V buffer (nothing is staged there before
+    // the first barrier of the loop) at piece ^ (row & 15), and reads the fragments back with ds_read_b128 — conflict-free
+    // for the 8-lane write groups and the 16-lane read groups. Same bits in the same registers.
+    {
+        T *qs = reinterpret_cast<T *>(smem + 2 * TILEB) + wave * 32 * D;
+        const int rsub = lane >> 4, pc = lane & 15;
+        vec8_t<T> t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 4 * i + rsub;
+            const bool ok = q0w + row < len;
+            t[i] = load8(qg + (static_cast<int64_t>(start) + (ok ? q0w + row : 0)) * p.q_tok_stride +
+                         static_cast<int64_t>(head) * D + pc * 8);
+            if (!ok) t[i] = vec8_t<T>{};
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 4 * i + rsub;
+            *reinterpret_cast<vec8_t<T> *>(qs + row * D + ((pc ^ (row & 15)) << 3)) = t[i];
+        }
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk)
+            qf[kk] = *reinterpret_cast<const vec8_t<T> *>(qs + l32 * D + (((2 * kk + hf) ^ (l32 & 15)) << 3));
+        // the reads have returned before any wave's DMA of tile 1 (issued behind the loop's first barrier) can land here
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     for (int tile = 0; tile < ntiles; ++tile) {
         const int key0 = tile * kBK;
         const int buf = tile & 1;

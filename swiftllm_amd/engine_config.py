@@ -66,10 +66,10 @@ class EngineConfig:
         # batches of <= 2 sequences: the qkv and up/gate projections sum the previous projection's slabs themselves
         # (csrc/gemm_tiny.hip), 5 launches per layer instead of 7
         tiny_decode_batches=True,
-        # decode batches of <= 32 sequences, bfloat16: o_proj — and down_proj up to 8 sequences — finish their rows INSIDE the
+        # decode batches of <= 32 sequences, bfloat16: o_proj — and down_proj up to 16 sequences — finish their rows INSIDE the
         # workgroup that owns them (csrc/gemm_rows.hip: K split across the 8 waves, residual add in the epilogue: no slabs,
         # no consumer launch), and the projection that follows applies the norm weight and the 1/rms itself while it stages
-        # the raw residual rows ("norm on the fly", gemm_skinny.hip NF): 6 launches per layer at batch 32, 5 up to batch 8
+        # the raw residual rows ("norm on the fly", gemm_skinny.hip NF): 6 launches per layer at batch 32, 5 up to batch 16
         rows_decode=True,
         # ONE decoding sequence: the whole transformer stack of the step as one persistent launch (csrc/decode_engine.hip: a
         # loader wave per CU streams that CU's rows of every projection by LDS-DMA, three consumer waves compute, operator
@@ -80,6 +80,11 @@ class EngineConfig:
         # third copy of the layer weights (13.9 GB for Llama-3-8B) when on.
         decode_engine=False,
         pin_swap_memory=True,           # host swap pool in pinned memory (falls back to pageable when the host refuses)
+        # the serving loop (server/engine.py) keeps the interpreter's cyclic collector out of its busy iterations: the model's
+        # long-lived objects are frozen out of the collector's working set when the loop starts, young generations are
+        # collected when the loop goes idle (or every 256 busy iterations), a full collection every 4096 — what bench.py's
+        # timed region does around its K steps (the benchmark measures what the server does)
+        pause_gc_while_serving=True,
     )
 
     # Tokens per KV block the HIP kernels are built for (csrc/paged_attn.hip kBlk, kvcache.hip): one 16-token block

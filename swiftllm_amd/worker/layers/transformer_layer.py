@@ -22,7 +22,11 @@ Very small decode batches (tiny_decode_batches; policy limit <= 2 sequences = ke
 take up to 4; bfloat16 only, as it rides on the deferred norm): the two consumers above disappear altogether — the
 qkv projection and the up/gate projection sum the previous projection's slabs themselves while their first weight
 tiles are in flight (kernels/linear.py: linear_splitk_from_splitk / linear_silu_gate_from_splitk, csrc/gemm_tiny.hip),
-the residual stream ping-pongs between two buffers: 5 launches per layer instead of 7.
+the residual stream ping-pongs between two buffers: 5 launches per layer instead of 7. Since r05 this path is the FALLBACK
+at these batch sizes, by measurement: with rows_decode on (the default) the row-owned layer below also runs 5 launches and
+is faster — 78.5 vs 82.0 us for the projection side of a layer at one sequence, 82.9 for the consumer path
+(profiles/r06b_rows_ab.jsonl, tools/gemm_rows_micro.py --layer) — so a layer only receives split-K slabs, and this path
+only runs, where the row-owned kernels do not take the shape (or rows_decode is switched off, as its tests do).
 
 Row-owned projections (rows_decode, bfloat16, on the deferred-norm path): o_proj for <= ROWS_O_MAX_M sequences and down_proj for
 <= ROWS_DOWN_MAX_M add themselves into the residual buffer in their own epilogue (kernels/linear.py: linear_rows_add,
@@ -66,7 +70,6 @@ class LlamaTransformerLayer:
         self.decoding_piggyback_stream = decoding_piggyback_stream
         self.layer_id = layer_id
         self.skinny = bool(getattr(engine_config, "use_skinny_gemm", False))
-        self._cur_state = None      # the infer state of the forward in progress (the post-attention half reads it)
         self._qkv_splits = None     # k-splits the skinny GEMM picks for the fused qkv projection (cached)
         self._tiny_ok = None        # can this layer run the tiny-batch (<= TINY_POLICY_M sequences) path (cached)
 
@@ -90,7 +93,6 @@ class LlamaTransformerLayer:
     def forward(self, input_embds, residual_buf: torch.Tensor, k_cache: torch.Tensor,
                 v_cache: torch.Tensor, block_table: torch.Tensor, infer_state):
         cfg, ecfg, w, st = self.model_config, self.engine_config, self.weight, infer_state
-        self._cur_state = st
 
         # residual_buf <- input_embds + residual_buf ; input_embds <- rmsnorm(residual_buf)
         row_scale = None
@@ -143,10 +145,11 @@ class LlamaTransformerLayer:
         round(r * attn_norm) with the 1/rms pending -> slab-fed attention -> the rest of the layer."""
         cfg, ecfg, w = self.model_config, self.engine_config, self.weight
         qkv, pend = linear_splitk_nf(residual_buf, w.attn_norm, w.qkv_proj, cfg.rms_norm_eps)
-        o = torch.empty_like(residual_buf)
+        # (the attention output is [tokens, heads * head_dim], which need not be the residual's width)
+        o = residual_buf.new_empty((residual_buf.shape[0], cfg.num_q_heads * cfg.head_dim))
         paged_attention_from_qkv_splitk(qkv, k_cache, v_cache, block_table, cfg, ecfg, st, self.layer_id, o,
                                         row_scale=pend)
-        return self._forward_after_attention(o, residual_buf, True)
+        return self._forward_after_attention(o, residual_buf, True, st)
 
     def _qkv_splits_even(self) -> bool:
         """linear_splitk_nf takes even K splits only (set by _deferred_attn_norm_ok, which every caller checked first)."""
@@ -186,7 +189,7 @@ class LlamaTransformerLayer:
                                                         st.seq_block_size, st.num_seq_blocks, w.o_proj,
                                                         residual_buf.dtype)
         else:
-            o = torch.empty_like(residual_buf)
+            o = residual_buf.new_empty((m, cfg.num_q_heads * cfg.head_dim))
             paged_attention_from_qkv_splitk(qkv, k_cache, v_cache, block_table, cfg, ecfg, st, self.layer_id, o,
                                             row_scale=pend)
             attn_out = linear_splitk(o, w.o_proj)
@@ -213,7 +216,7 @@ class LlamaTransformerLayer:
             if isinstance(qkv, SplitKPartials):
                 paged_attention_from_qkv_splitk(qkv, k_cache, v_cache, block_table, cfg, ecfg, st, self.layer_id,
                                                 input_embds, row_scale=row_scale)
-                return self._forward_after_attention(input_embds, residual_buf, fast)
+                return self._forward_after_attention(input_embds, residual_buf, fast, st)
         assert row_scale is None, "deferred RMSNorm reached a path that cannot apply it"
         if fast and fused_rope_store and w.qkv_proj is not None:
             if qkv is None:     # (else: the projection above came back as a plain tensor — batches beyond the slab
@@ -262,11 +265,10 @@ class LlamaTransformerLayer:
             assert not st.ignore_kvcache
             paged_attention(q, k_cache, v_cache, block_table, cfg, ecfg, st, self.layer_id, o)
         q = k = v = None
-        return self._forward_after_attention(input_embds, residual_buf, fast)
+        return self._forward_after_attention(input_embds, residual_buf, fast, st)
 
-    def _forward_after_attention(self, input_embds, residual_buf, fast: bool):
+    def _forward_after_attention(self, input_embds, residual_buf, fast: bool, st):
         cfg, w = self.model_config, self.weight
-        st = self._cur_state
         if (fast and st is not None and self._rows_applies(st, residual_buf, w.o_proj, input_embds, self.ROWS_O_MAX_M)
                 and nf_ok(residual_buf, w.up_gate_proj, w.ffn_norm) and w.up_gate_proj.shape[0] % 64 == 0):
             # o_proj adds itself into the residual; the SiLU-gate GEMM normalises the raw rows on the fly

@@ -91,7 +91,7 @@ class LlamaModel:
         self._meta_dev = None       # its device twin (fixed address: hipGraph replays read it)
         self._meta_done = None
         self._num_slots = 256        # CUs: one 8-wave paged-attention workgroup each
-        self._decode_graphs = {}     # (batch, split width, split count) -> _DecodeGraph, in LRU order
+        self._decode_graphs = {}     # (batch, split width, split count, logits kept) -> _DecodeGraph, in LRU order
         self._lookahead = None       # _DecodeLookahead of the step that is expected next (graph replay only)
         self._decode_lookahead = True    # (tests switch it off to hold the fast path to the plain one)
         # optional callable, invoked by forward() in the calling thread once the step's kernels are enqueued and before
@@ -233,9 +233,10 @@ class LlamaModel:
         ONE pool (_forward_decode_graph), so the largest batch sets its size. 25 % + 16 MiB on top for the allocator's
         rounding. Falls back to the r04 formula when the throw-away pool cannot be built."""
         cfg, ecfg = self.model_config, self.engine_config
-        b = int(ecfg.max_batch_size)
+        # the largest CAPTURED batch: max_batch_size rounded up to its replay bucket (up to 15 inert rows more, ADVICE r05)
+        b = min(self._decode_batch_bucket(int(ecfg.max_batch_size)), int(ecfg.max_seqs_in_block_table))
         formula = b * cfg.vocab_size * 8 + b * (cfg.hidden_size + cfg.ffn_inter_dim) * 64 + (64 << 20)
-        if b <= 0 or b > ecfg.max_seqs_in_block_table:
+        if b <= 0:
             return formula
         saved = (self.k_cache, self.v_cache, self.gpu_block_manager, self.cpu_block_manager, ecfg.use_hip_graph)
         try:
@@ -253,7 +254,11 @@ class LlamaModel:
             self.forward([[0]] * b, list(range(b)), [1] * b)
             torch.cuda.synchronize()
             peak = torch.cuda.max_memory_allocated() - base
-            measured = int(peak * 1.25) + (16 << 20)
+            # + what every cached graph keeps alive in the shared pool after its capture: its sampled-token tensor (the
+            # [B, vocab] logits are retained only while a test taps them — _forward_decode_graph), rounded to the
+            # allocator's 512-byte granule, for a full replay cache
+            retained = self._MAX_DECODE_GRAPHS * (-(-b * 8 // 512) * 512 + 512)
+            measured = int(peak * 1.25) + (16 << 20) + retained
             print(f"[Model.profile] decode activations at batch {b}: {peak / 2**20:.1f} MiB "
                   f"(hipGraph pool reserve {measured / 2**20:.1f} MiB; r04 formula: {formula / 2**20:.1f} MiB)")
             return measured
@@ -461,11 +466,13 @@ class LlamaModel:
     def _forward_decode_graph(self, plan: BatchPlan, dev: dict) -> torch.Tensor:
         sbs, nsb_cap = self._graph_bucket(plan)
         use_engine = self._engine is not None and plan.batch_size == 1
-        key = (1, 0, 0) if use_engine else (plan.batch_size, sbs, nsb_cap)    # (the engine has one launch geometry)
-        entry = self._decode_graphs.pop(key, None)
-        plan.seq_block_size, plan.num_seq_blocks = sbs, nsb_cap
         tap = self.post_layer.logits_tap
         tap_len = len(tap) if tap is not None else 0
+        # (the engine has one launch geometry; a graph captured while a test taps the logits keeps its [B, vocab] tensor
+        # alive in the shared pool, one captured without the tap does not — up to 65 MB per graph at 256 sequences)
+        key = ((1, 0, 0) if use_engine else (plan.batch_size, sbs, nsb_cap)) + (tap is not None,)
+        entry = self._decode_graphs.pop(key, None)
+        plan.seq_block_size, plan.num_seq_blocks = sbs, nsb_cap
         if entry is None:
             self.graph_captures += 1
             state = self._make_infer_state(plan, dev, False)
@@ -486,7 +493,9 @@ class LlamaModel:
             entry.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(entry.graph, pool=self._graph_pool):
                 entry.out_tokens = self._forward(dev["input_ids"], state)
-            entry.logits = self.post_layer.last_logits
+            entry.logits = self.post_layer.last_logits if tap is not None else None
+            if tap is None:
+                self.post_layer.last_logits = None      # (drop the last reference: the buffer returns to the shared pool)
             entry.seq_block_size, entry.num_seq_blocks = sbs, nsb_cap
             entry.engine = use_engine
             if tap is not None:

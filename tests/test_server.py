@@ -158,6 +158,44 @@ def test_engine_generates_streams_and_frees(piggyback):
         assert all(not (isinstance(c[0], int) and c[0] > 0 and c[1] > 0) for c in model.calls)
 
 
+def test_serving_loop_keeps_the_cyclic_collector_out_of_its_busy_iterations():
+    """EngineConfig tuning pause_gc_while_serving (default on): automatic collection is off inside every
+    forward the loop runs and restored when the loop stops; with the switch off the loop leaves the collector alone."""
+    import gc
+
+    class GcModel(FakeModel):
+        def __init__(self):
+            super().__init__()
+            self.gc_enabled_in_forward = []
+
+        def forward(self, input_ids, seq_ids, decoding_lens):
+            self.gc_enabled_in_forward.append(gc.isenabled())
+            return super().forward(input_ids, seq_ids, decoding_lens)
+
+    async def run(tuning):
+        model = GcModel()
+        eng = Engine(_cfg(tuning=tuning), model=model)
+        await eng.initialize()
+        loops = asyncio.ensure_future(eng.start_all_event_loops())
+        await asyncio.wait_for(eng.add_request_and_wait(RawRequest("", 5, [3, 4])), timeout=20)
+        loops.cancel()
+        try:
+            await loops
+        except (asyncio.CancelledError, Exception):
+            pass
+        for _ in range(200):                 # the model thread restores the collector on its way out
+            if eng._model_thread is None or not eng._model_thread.is_alive():
+                break
+            await asyncio.sleep(0.01)
+        return model
+    assert gc.isenabled()
+    model = asyncio.run(run(None))
+    assert model.gc_enabled_in_forward and not any(model.gc_enabled_in_forward)
+    assert gc.isenabled() and gc.get_freeze_count() == 0
+    model = asyncio.run(run(dict(pause_gc_while_serving=False)))
+    assert model.gc_enabled_in_forward and all(model.gc_enabled_in_forward)
+
+
 class HookedModel(FakeModel):
     """A data plane with LlamaModel's `after_launch_hook`: fires it once its "kernels are enqueued", then "waits for
     the GPU" (GIL released) before returning the tokens. Records what the clients had seen at both moments."""

@@ -268,7 +268,7 @@ class LlamaModel:
         finally:
             self.k_cache, self.v_cache, self.gpu_block_manager, self.cpu_block_manager, ecfg.use_hip_graph = saved
             self._lookahead = None
-            self._decode_graphs.clear()
+            self._drop_decode_graphs()
             torch.cuda.empty_cache()
 
     @torch.inference_mode()
@@ -295,7 +295,7 @@ class LlamaModel:
         self.cpu_block_manager = BlockManager("CPU", ecfg.num_cpu_blocks,
                                               ecfg.max_seqs_in_block_table, ecfg.max_blocks_per_seq,
                                               ecfg.block_size, self.device)
-        self._decode_graphs.clear()
+        self._drop_decode_graphs()
         self._lookahead = None
 
     def _init_to_get_rotary(self):
@@ -336,7 +336,7 @@ class LlamaModel:
             self._meta_host_np = self._meta_host.numpy()
             self._meta_dev = torch.empty(cap, dtype=torch.int32, device=self.device)
             self._meta_done = torch.cuda.Event()
-            self._decode_graphs.clear()     # captured graphs point into the old buffer
+            self._drop_decode_graphs()     # captured graphs point into the old buffer
         plan.pack_into(self._meta_host_np)
         self._meta_dev[:total].copy_(self._meta_host[:total], non_blocking=True)
         self._meta_done.record()
@@ -349,7 +349,7 @@ class LlamaModel:
                                       self.model_config.head_dim, nsb) // 4
             if self._scratch is None or self._scratch.numel() < need:
                 self._scratch = torch.empty(need, dtype=torch.float32, device=self.device)
-                self._decode_graphs.clear()
+                self._drop_decode_graphs()
         return LlamaInferState(
             batch_size=plan.batch_size, num_tokens=plan.num_tokens,
             seq_ids=dev["seq_ids"], softmax_scale=self.model_config.head_dim ** -0.5,
@@ -406,11 +406,22 @@ class LlamaModel:
         torch.cuda.synchronize()
         self._engine.reset()
         self._engine = None
-        self._decode_graphs.clear()
+        self._drop_decode_graphs()
         self._lookahead = None
         self.engine_fallbacks += 1
 
     # ---- hipGraph replay of pure-decode steps ------------------------------------------------------------
+    def _drop_decode_graphs(self):
+        """Forget every captured decode graph (their buffers moved, or the pool / engine they were captured against is gone)
+        AND the private memory pool they shared. The pool handle must go with them: once its last graph is destroyed the
+        caching allocator marks the pool freeable (use_count 0) but keeps it on its books until the next cache flush, and a
+        new capture into that id trips `it->second->use_count > 0` (HIPCachingAllocator.cpp) — met in r06 by the serving
+        sweep (tools/serve_bench.py --sweep: the flash-decoding scratch grew after graphs had been captured) and by
+        bench.py's engine leg. The next capture opens a fresh pool; the old one's memory returns to the device on the
+        allocator's next flush."""
+        self._decode_graphs.clear()
+        self._graph_pool = None
+
     _MAX_DECODE_GRAPHS = 48     # LRU bound of the replay cache (each graph pins its activations + [B, vocab] logits)
 
     def _graph_bucket(self, plan: BatchPlan):

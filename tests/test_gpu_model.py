@@ -638,6 +638,50 @@ def test_large_decode_batches_replay_their_hip_graph_bit_for_bit(tmp_path, batch
         assert torch.equal(a, b)
 
 
+def test_graphs_are_recaptured_after_the_flash_decoding_scratch_grows(tmp_path):
+    """A server meets this: decode graphs exist (one short sequence), then a step needs a larger flash-decoding scratch (more
+    sequences, split contexts) — the captured graphs point into the old buffer and are dropped. The shared private pool must
+    be dropped WITH them: a pool whose last graph is gone sits on the caching allocator's books with use_count 0, and the
+    next capture into the same id tripped `it->second->use_count > 0` (r06: tools/serve_bench.py --sweep crashed the model
+    thread with it; r05 introduced the shared pool). The steps after the drop replay fresh captures and equal eager launches."""
+    cfg = synth.make_config(num_hidden_layers=2, hidden_size=1024, num_attention_heads=8, num_key_value_heads=2,
+                            intermediate_size=2048, vocab_size=512, max_position_embeddings=1024)
+    sd = synth.make_state_dict(cfg, seed=23, dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(4)
+    lens0 = [300, 280, 310, 290, 305, 270]
+    prompts = [torch.randint(0, cfg["vocab_size"], (n,), generator=g).tolist() for n in lens0]
+    runs = {}
+    for graph in (False, True):
+        model = _make_model(tmp_path / f"g{int(graph)}", cfg, sd, 200, max_blocks_per_seq=32, max_tokens_in_batch=2048,
+                            max_batch_size=8, max_seqs_in_block_table=16, dtype="bfloat16", use_hip_graph=graph)
+        seq_ids = list(range(len(prompts)))
+        toks = model.forward(prompts, seq_ids, [])
+        lens = list(lens0)
+        out = []
+        for step in range(2):                   # one sequence alone: a graph (and a small scratch) exists
+            lens[0] += 1
+            toks[0] = model.forward([[toks[0]]], [0], [lens[0]])[0]
+            out.append(toks[0])
+        pools = []
+        if graph:
+            assert len(model._decode_graphs) >= 1
+            pools.append(model._graph_pool)
+            scratch0 = model._scratch.numel() if model._scratch is not None else 0
+        for step in range(3):                   # all six: a larger scratch, every graph dropped, new captures
+            lens = [n + 1 for n in lens]
+            toks = model.forward([[t] for t in toks], seq_ids, list(lens))
+            out.append(list(toks))
+        if graph:
+            assert model._scratch is not None and model._scratch.numel() > scratch0, "the scenario did not grow the scratch"
+            assert model._graph_pool is not None and model._graph_pool != pools[0]
+        runs[graph] = (out, [t.clone() for t in model.post_layer.logits_tap])
+        del model
+        torch.cuda.empty_cache()
+    assert runs[True][0] == runs[False][0]
+    for a, b in zip(runs[True][1], runs[False][1]):
+        assert a.shape == b.shape and torch.equal(a, b)
+
+
 @pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
 def test_decode_batch_buckets_replay_equals_exact_eager_launches(tmp_path, dtype):
     """hipGraph replay rounds a pure-decode batch up to its bucket with inert rows (worker/model.py: _decode_batch_bucket):

@@ -45,7 +45,7 @@ def main():
     wall = (time.perf_counter() - t0) / a.steps * 1e3
     # stamps: eager launches (a captured graph has the NULL pointer baked in)
     model.engine_config.use_hip_graph = False
-    model._decode_graphs.clear()
+    model._drop_decode_graphs()
     model._lookahead = None
     stamps = model._engine.enable_debug_stamps()
     seg = torch.zeros(16, dtype=torch.float64)      # mean time from the previous stamp to stamp k (k = 0: from the previous layer's end)

@@ -75,6 +75,8 @@ async def run(model, a, piggyback, eng=None, seed=7):
             if first is None:
                 first = time.perf_counter()
         t1 = time.perf_counter()
+        if first is None:           # the engine ended the stream without a token (its model thread died: see stderr)
+            raise RuntimeError("a request came back without tokens")
         ttft.append(first - t0)
         norm.append((t1 - t0) / max(1, n))      # end-to-end latency per output token of this request
         if n > 1:

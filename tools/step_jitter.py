@@ -31,7 +31,7 @@ def main():
                           reserved_gb=round(torch.cuda.memory_reserved() / 1e9, 3),
                           allocated_gb=round(torch.cuda.memory_allocated() / 1e9, 3))), flush=True)
     for trial in range(a.trials):
-        model._decode_graphs.clear()
+        model._drop_decode_graphs()
         model._lookahead = None
         run = bench.DecodeRun(model, a.batch, cfg["vocab_size"], seed=3 + trial)
         run.jump_to(1088 - a.steps // 2 - 8)

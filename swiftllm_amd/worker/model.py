@@ -107,7 +107,9 @@ class LlamaModel:
         # the one-sequence persistent decode step (worker/decode_engine.py); None: shape / device / memory / switch say no
         self._engine = None
         self.engine_fallbacks = 0    # steps re-run on the multi-launch path after the engine reported a timed-out hand-off
-        self.graph_captures = 0      # hipGraph captures so far (each = one warm-up forward + one capture): serving reports it
+        self.graph_captures = 0      # hipGraph captures so far (the first at a batch bucket = one warm-up forward + one capture)
+        self.graph_capture_s = 0.0   # host seconds spent in them: serving reports both
+        self._warmed_buckets = set()
 
     # ------------------------------------------------------------------------------------------------
     @torch.inference_mode()
@@ -421,8 +423,14 @@ class LlamaModel:
         allocator's next flush."""
         self._decode_graphs.clear()
         self._graph_pool = None
+        self._warmed_buckets.clear()     # (workspaces may have been re-sized: warm up again before the next capture)
 
-    _MAX_DECODE_GRAPHS = 48     # LRU bound of the replay cache (each graph pins its activations + [B, vocab] logits)
+    # LRU bound of the replay cache. Since r06b a cached graph pins only its sampled-token tensor in the shared pool (the
+    # [B, vocab] logits are kept only under a test's tap), so the bound is about host-side graph objects, not HBM. 48 (r05)
+    # thrashed under a serving sweep with ShareGPT-like lengths at max batch 256: 14 batch buckets x ~5 single-split widths
+    # + the split geometries of small batches = well over 100 live keys, 23-53 captures per 1000 forwards at 40-200 req/s
+    # (profiles/r06b_serve_sweep_sharegpt_*.jsonl).
+    _MAX_DECODE_GRAPHS = 256
 
     def _graph_bucket(self, plan: BatchPlan):
         """Captured launch geometry must cover every replay, and the number of distinct geometries a long-running
@@ -450,15 +458,17 @@ class LlamaModel:
     def _decode_batch_bucket(self, batch: int) -> int:
         """Captured batch size that serves a pure-decode batch of `batch` sequences. The replay cache is keyed on the batch
         size, and a server's batch drifts by one sequence at a time: keyed on the EXACT size (r01-r04) every new size paid a
-        warm-up forward plus a capture. Sizes are rounded up — to a multiple of 8 up to 64 sequences, of 16 beyond (the
-        projections' cost moves in 32-token blocks there) — and the surplus rows are INERT: length-0 sequences, which every
+        warm-up forward plus a capture. Sizes are rounded up — to a multiple of 8 up to 32 sequences, of 16 up to 64, of 32
+        beyond (the projections' cost moves in 32-token blocks there) — and the surplus rows are INERT: length-0 sequences, which every
         decode kernel treats as a no-op (paged attention: the workgroup exits before its prologue; rotary / KV store: nothing
         read, nothing stored; the projections, norms and the sampler are row-independent, so whatever an inert row holds
         never reaches a real one). 1 and 2 stay exact (their own launch path). The reference has no graphs
         (swiftllm/worker/model.py:228-249 launches eagerly); results are those of the exact-size launch."""
         if batch <= 2:
             return batch
-        step = 8 if batch <= 64 else 16
+        # r06b: 16 between 32 and 64 (the medium kernels serve two token blocks whatever the count), 32 beyond 64 (the wide
+        # GEMMs and the library work in 32-token blocks: 129 -> 160 costs what 144 did) — 14 buckets up to 256 instead of 22
+        step = 8 if batch <= 32 else 16 if batch <= 64 else 32
         return -(-batch // step) * step
 
     def _plan_decode(self, seq_ids_list: List[int], lens: List[int], tokens, pad: bool) -> BatchPlan:
@@ -486,14 +496,19 @@ class LlamaModel:
         plan.seq_block_size, plan.num_seq_blocks = sbs, nsb_cap
         if entry is None:
             self.graph_captures += 1
+            t_cap = time.perf_counter()
             state = self._make_infer_state(plan, dev, False)
-            # one eager run on a side stream first (library handles, workspaces, allocator pools):
-            # nothing may be lazily initialised while the stream is capturing
-            warm = torch.cuda.Stream()
-            warm.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(warm):
-                self._forward(dev["input_ids"], state)
-            torch.cuda.current_stream().wait_stream(warm)
+            # one eager run on a side stream first (library handles, workspaces, allocator pools): nothing may be lazily
+            # initialised while the stream is capturing. Once per BATCH BUCKET (r06b): a new split geometry at a batch size
+            # that has been captured before launches the same kernels on the same shapes — only the attention grid moves.
+            warm_key = (key[0], use_engine, tap is not None)
+            if warm_key not in self._warmed_buckets:
+                warm = torch.cuda.Stream()
+                warm.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(warm):
+                    self._forward(dev["input_ids"], state)
+                torch.cuda.current_stream().wait_stream(warm)
+                self._warmed_buckets.add(warm_key)
             while len(self._decode_graphs) >= self._MAX_DECODE_GRAPHS:      # least recently used first
                 self._decode_graphs.pop(next(iter(self._decode_graphs)))
             if self._graph_pool is None:
@@ -511,6 +526,7 @@ class LlamaModel:
             entry.engine = use_engine
             if tap is not None:
                 del tap[tap_len:]               # what the warm-up run and the capture appended
+            self.graph_capture_s += time.perf_counter() - t_cap
         self._decode_graphs[key] = entry        # (re)inserted last = most recently used
         entry.graph.replay()
         n = plan.real_seqs

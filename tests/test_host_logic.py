@@ -377,8 +377,8 @@ def test_graph_bucket_keeps_splits_balanced_and_few():
 
 def test_decode_batch_buckets_and_inert_rows():
     """hipGraph replay keys on the batch rounded up to a bucket (worker/model.py: _decode_batch_bucket) and fills the
-    surplus rows with inert sequences: few distinct buckets over 1..256, never smaller than the batch, at most 15 rows of
-    padding, thresholds of the launch paths (2 / 32 / 64 / 256) are bucket boundaries; the padded plan has the layout
+    surplus rows with inert sequences: few distinct buckets over 1..256 (14 since r06b), never smaller than the batch, at
+    most 7 / 15 / 31 rows of padding up to 32 / 64 / 256 sequences, thresholds of the launch paths (2 / 32 / 64 / 256) are bucket boundaries; the padded plan has the layout
     of an exact plan of the bucket size (a captured graph finds its metadata at fixed addresses), length 0 / position -1
     / token 0 in the inert rows, and the planner's split width does not see them."""
     import types
@@ -388,10 +388,10 @@ def test_decode_batch_buckets_and_inert_rows():
     m.model_config = types.SimpleNamespace(num_kv_heads=8)
     m._num_slots = 256
     buckets = {b: m._decode_batch_bucket(b) for b in range(1, 257)}
-    assert all(v >= b and v - b <= 15 for b, v in buckets.items())
-    assert buckets[1] == 1 and buckets[2] == 2 and buckets[3] == 8 and buckets[32] == 32 and buckets[33] == 40
-    assert buckets[64] == 64 and buckets[65] == 80 and buckets[250] == 256 and buckets[256] == 256
-    assert len(set(buckets.values())) <= 24
+    assert all(v >= b and v - b <= (7 if b <= 32 else 15 if b <= 64 else 31) for b, v in buckets.items())
+    assert buckets[1] == 1 and buckets[2] == 2 and buckets[3] == 8 and buckets[32] == 32 and buckets[33] == 48
+    assert buckets[64] == 64 and buckets[65] == 96 and buckets[129] == 160 and buckets[250] == 256 and buckets[256] == 256
+    assert sorted(set(buckets.values())) == [1, 2, 8, 16, 24, 32, 48, 64, 96, 128, 160, 192, 224, 256]
     for limit in (32, 64, 128, 256):     # a batch on one side of a launch-path threshold is never padded across it
         assert all(v <= limit for b, v in buckets.items() if b <= limit)
     lens = [1100, 37, 5]

@@ -86,7 +86,7 @@ async def run(model, a, piggyback, eng=None, seed=7):
         delays.append(t)
         if a.rate > 0:
             t += rng.expovariate(a.rate)
-    caps0, fwd0 = getattr(model, "graph_captures", 0), eng.num_forwards
+    caps0, fwd0, cap_s0 = getattr(model, "graph_captures", 0), eng.num_forwards, getattr(model, "graph_capture_s", 0.0)
     t0 = time.perf_counter()
     await asyncio.gather(*(one(p, gl, d) for p, (_, gl), d in zip(prompts, lens, delays)))
     dt = time.perf_counter() - t0
@@ -108,6 +108,7 @@ async def run(model, a, piggyback, eng=None, seed=7):
             # every capture = one eager warm-up forward + one capture (worker/model.py: _forward_decode_graph); keyed on batch
             # BUCKETS and split-geometry buckets since r05
             "graph_captures": caps, "graph_captures_per_1000_forwards": round(1000.0 * caps / fwds, 2),
+            "graph_capture_s": round(getattr(model, "graph_capture_s", 0.0) - cap_s0, 3),
             "graphs_cached": len(getattr(model, "_decode_graphs", {}) or {}),
             "ttft_ms_p50": round(ttft[len(ttft) // 2] * 1e3, 1), "ttft_ms_max": round(ttft[-1] * 1e3, 1),
             "tpot_ms_p50": round(tpot[len(tpot) // 2] * 1e3, 2) if tpot else None,

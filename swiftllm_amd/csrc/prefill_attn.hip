@@ -60,6 +60,7 @@ struct PrefillParams {
     int64_t q_tok_stride, k_tok_stride, v_tok_stride, o_tok_stride;
 };
 
+constexpr float kLazyMax = 4.0f; // see the softmax step of the kernels (p <= 16)
 constexpr int kBQ = 128; // q rows per workgroup
 constexpr int kBK = 64;  // keys per LDS tile
 
@@ -216,12 +217,14 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(PrefillParams p) {
         mfma_results_ready<8>(st[1]);
         // causal mask on the diagonal tiles (keys beyond len are > every valid q row as well)
         if (key0 + kBK - 1 > q0w) {
+            const int dmask = qrow - key0 - 4 * hf;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = key0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                    if (key > qrow) st[t][r] = kNegBig;
+                    // key > qrow with key = key0 + 32 t + (r & 3) + 8 (r >> 2) + 4 hf: a compile-time constant against ONE
+                    // per-lane value (one compare + one select per element; r01-r06a rebuilt the key first: three)
+                    if ((r & 3) + 8 * (r >> 2) + t * 32 > dmask) st[t][r] = kNegBig;
                 }
         }
         // ---- online softmax: this lane owns q row l32, keys split with lane^32 ---------------------
@@ -231,7 +234,14 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(PrefillParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx * c);
+        // lazy running maximum (r06b): a row moves its maximum only when the tile raised it by more than kLazyMax (base-2
+        // exponent units), so p stays <= 2^kLazyMax instead of <= 1 — 16-bit floats round p to the same RELATIVE precision at
+        // either scale, l and O accumulate in fp32 — and alpha is exactly 1 for that row: the 64-multiply rescale of O below
+        // then fires on the first tile or two of a row block instead of on most tiles (any of a wave's 32 rows setting a
+        // record). Decided per ROW, so a row's arithmetic still depends on its own scores only (the causality test holds
+        // bit for bit).
+        const float m_cand = fmaxf(m_run, mx * c);
+        const float m_new = m_cand - m_run > kLazyMax ? m_cand : m_run;
         const float alpha = fast_exp2(m_run - m_new);
         m_run = m_new;
         float psum = 0.f;
@@ -494,12 +504,14 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_dma_kernel(PrefillParams 
         mfma_results_tie(st[0]);
         mfma_results_ready<8>(st[1]);
         if (key0 + kBK - 1 > q0w) {
+            const int dmask = qrow - key0 - 4 * hf;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = key0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                    if (key > qrow) st[t][r] = kNegBig;
+                    // key > qrow with key = key0 + 32 t + (r & 3) + 8 (r >> 2) + 4 hf: a compile-time constant against ONE
+                    // per-lane value (one compare + one select per element; r01-r06a rebuilt the key first: three)
+                    if ((r & 3) + 8 * (r >> 2) + t * 32 > dmask) st[t][r] = kNegBig;
                 }
         }
         float mx = st[0][0];
@@ -508,7 +520,14 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_dma_kernel(PrefillParams 
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx * c);
+        // lazy running maximum (r06b): a row moves its maximum only when the tile raised it by more than kLazyMax (base-2
+        // exponent units), so p stays <= 2^kLazyMax instead of <= 1 — 16-bit floats round p to the same RELATIVE precision at
+        // either scale, l and O accumulate in fp32 — and alpha is exactly 1 for that row: the 64-multiply rescale of O below
+        // then fires on the first tile or two of a row block instead of on most tiles (any of a wave's 32 rows setting a
+        // record). Decided per ROW, so a row's arithmetic still depends on its own scores only (the causality test holds
+        // bit for bit).
+        const float m_cand = fmaxf(m_run, mx * c);
+        const float m_new = m_cand - m_run > kLazyMax ? m_cand : m_run;
         const float alpha = fast_exp2(m_run - m_new);
         m_run = m_new;
         float psum = 0.f;

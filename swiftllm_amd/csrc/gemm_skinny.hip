@@ -81,7 +81,7 @@ template <typename T, int MODE>
 __device__ __forceinline__ void gemm_epilogue(const float16_t &acc, void *__restrict__ out_, T *wtiles,
                                               int wave_pitch, int wave, int lane, bool is_gate, bool tile_ok,
                                               int col0, int n0, int ksplit, int M, int N, int64_t out_stride,
-                                              float rs = 1.0f) {
+                                              float rs = 1.0f, int gate_waves_off = 2) {
     const int l32 = lane & 31;
     const int hf = lane >> 5;
     if constexpr (MODE == kGemmSiluGate) {
@@ -97,7 +97,7 @@ __device__ __forceinline__ void gemm_epilogue(const float16_t &acc, void *__rest
         }
         __syncthreads();
         if (!is_gate && tile_ok && l32 < M) {
-            const T *act = wtiles + (wave + 2) * wave_pitch;
+            const T *act = wtiles + (wave + gate_waves_off) * wave_pitch;   // the gate tile of this wave's columns
             typedef T vec4 __attribute__((ext_vector_type(4)));
             T *o = static_cast<T *>(out_) + static_cast<int64_t>(l32) * out_stride + col0 + 4 * hf;
 #pragma unroll
@@ -239,11 +239,15 @@ constexpr int kRing = 3;
 // with the tile's x loads, the staging pass multiplies and rounds (the bits of splitk_add_scale_kernel) and accumulates
 // sum r^2 per row in fp32 — every workgroup redundantly, it sees all of x anyway.
 template <typename T, int MODE, bool PACKED = false, int RD = kRing, int NWV = kGemmWaves, bool NF = false>
-// 2 waves per SIMD: the ring holds RD x 8 KiB of W per wave in registers (~220 VGPRs at RD = 3)
-__global__ __launch_bounds__(NWV * 64, 2) void gemm_skinny_ring_kernel(
+// 2 waves per SIMD: the ring holds RD x 8 KiB of W per wave in registers (~220 VGPRs at RD = 3); the two-wave SiLU-gate
+// form stages twice the x rows per wave and runs one wave per SIMD (two workgroups per CU)
+__global__ __launch_bounds__(NWV * 64, NWV == 2 ? 1 : 2) void gemm_skinny_ring_kernel(
     void *__restrict__ out_, const T *__restrict__ x, const T *__restrict__ w, int M, int N, int K,
     int kc, int64_t x_stride, int64_t out_stride, GemmExtra fuse) {
-    static_assert(NWV == kGemmWaves || (NWV == 3 && PACKED && MODE == kGemmPartial), "3 waves: packed partial only");
+    static_assert(NWV == kGemmWaves || (NWV == 3 && PACKED && MODE == kGemmPartial) ||
+                      (NWV == 2 && PACKED && MODE == kGemmSiluGate),
+                  "3 waves: packed partial only; 2 waves: packed SiLU-gate only");
+    constexpr int HWV = NWV / 2;         // SiLU-gate: waves [0, HWV) own `up` tiles, [HWV, NWV) the matching `gate` tiles
     static_assert(!NF || (PACKED && MODE != kGemmDirect), "norm on the fly: packed SiLU-gate / partial only");
     constexpr int D = RD;
     constexpr int XL = (8 + NWV - 1) / NWV; // x row-groups (4 rows each) a wave stages per tile
@@ -254,8 +258,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_skinny_ring_kernel(
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool is_gate = MODE == kGemmSiluGate && wave >= 2;
-    const int col0 = MODE == kGemmSiluGate ? (blockIdx.x * 2 + (wave & 1)) * 32
+    const bool is_gate = MODE == kGemmSiluGate && wave >= HWV;
+    const int col0 = MODE == kGemmSiluGate ? (blockIdx.x * HWV + (wave % HWV)) * 32
                                            : (blockIdx.x * NWV + wave) * 32;
     const bool tile_ok = col0 < N; // barriers below: a wave without a tile still stages x and syncs
     const int n0 = tile_ok ? col0 + (is_gate ? N : 0) : 0;
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_skinny_ring_kernel(
             rs = 1.0f / sqrtf(ss / static_cast<float>(K) + fuse.eps); // rmsnorm.hip's formula
         }
         gemm_epilogue<T, MODE>(acc, out_, &lds[0][0], 32 * 40, wave, lane, is_gate, tile_ok, col0, n0, ksplit, M, N,
-                               out_stride, rs);
+                               out_stride, rs, HWV);
     } else {
         gemm_epilogue<T, MODE>(acc, out_, &lds[PACKED ? 0 : 2][0], 32 * kKT, wave, lane, is_gate, tile_ok, col0, n0,
                                ksplit, M, N, out_stride);
@@ -861,6 +865,21 @@ extern "C" int swl_gemm_skinny_packed_silu_gate_nf(void *out, const void *x, con
     f.eps = eps;
     const dim3 grid((I / 32 + 1) / 2, 1);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // r06b: up to 8 tokens, workgroups of ONE up tile + ONE gate tile (448 workgroups for Llama-3-8B instead of 224: every CU
+    // streams; one wave per SIMD, two workgroups per CU) — same K order per tile, hence the same bits. Each wave then stages
+    // twice the x rows, which costs more than the idle CUs from 9 tokens on (tools/gpu_silu_waves_ab.sh, four interleaved
+    // rounds, profiles/r06b_silu_gate_two_wave_groups_ab.jsonl: 39.2 vs 39.8 us at 1 token, 39.2 vs 40.0 at 8, 41.2 vs 40.3
+    // at 32). A/B switch: SWL_SILU_WAVES=2 / 4 forces one form for every M.
+    static const int forced = [] { const char *e = getenv("SWL_SILU_WAVES"); return !e ? 0 : e[0] == '2' ? 2 : e[0] == '4' ? 4 : 0; }();
+    const bool two_waves = forced ? forced == 2 : M <= 8;
+    if (two_waves && swl::use_ring(K)) {
+        SWL_DISPATCH_DTYPE(dtype, T, {
+            hipLaunchKernelGGL((swl::gemm_skinny_ring_kernel<T, swl::kGemmSiluGate, true, 3, 2, true>), dim3(I / 32, 1),
+                               dim3(128), 0, s, out, static_cast<const T *>(x), static_cast<const T *>(w_up_gate_packed), M,
+                               I, K, K, x_row_stride, out_row_stride, f);
+        });
+        return swl::check_launch();
+    }
     SWL_DISPATCH_DTYPE(dtype, T, {
         if (swl::use_ring(K))
             hipLaunchKernelGGL((swl::gemm_skinny_ring_kernel<T, swl::kGemmSiluGate, true, 3, swl::kGemmWaves, true>),

@@ -489,8 +489,10 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_dma_kernel(PrefillParams 
         if (key0 > q0w + 31) continue; // whole tile above this wave's diagonal
         const char *bufp = smem + buf * 2 * TILEB;
 
+        // (no s_setprio around the MFMA blocks here: with two free-running workgroups per CU the per-block priority flips
+        // of the r01-r06a kernels cost 1.4-1.7 % — profiles/r06b_prefill_attn_setprio_ab.jsonl; the guide's T5 says as much)
         float16_t st[2];
-        __builtin_amdgcn_s_setprio(1);
+        
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             st[t] = float16_t{};
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_dma_kernel(PrefillParams 
                 st[t] = mfma32(kf, qf[kk], st[t]);
             }
         }
-        __builtin_amdgcn_s_setprio(0);
+        
         mfma_results_tie(st[0]);
         mfma_results_ready<8>(st[1]);
         if (key0 + kBK - 1 > q0w) {
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_dma_kernel(PrefillParams 
                 for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
         }
 
-        __builtin_amdgcn_s_setprio(1);
+        
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -566,7 +568,7 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_dma_kernel(PrefillParams 
                     ot[dt] = mfma32(vf, pb, ot[dt]);
                 }
             }
-        __builtin_amdgcn_s_setprio(0);
+        
     }
 
     // ---- epilogue: as prefill_attn_kernel (whole-row stores through LDS) ------------------------------------------------------

@@ -56,6 +56,7 @@ struct PrefillParams {
     const void *v;
     const int *cu_seqlens;
     int num_seqs, H, KVH, num_q_blocks;
+    int hpw;    // LDS-DMA kernel: q-heads per workgroup (4, 2 or 1); num_q_blocks then counts blocks of (4 / hpw) * 32 rows
     float scale_log2e;
     int64_t q_tok_stride, k_tok_stride, v_tok_stride, o_tok_stride;
 };
@@ -351,31 +352,36 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_dma_kernel(PrefillParams 
     constexpr int TILEB = kBK * ROWB;           // 16 KiB per K or V tile image
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILEB];      // [buffer][K, V]; the O tiles of the epilogue
 
+    // r06b — the four waves of a workgroup are `hpw` q-heads of the kv-head x 4/hpw row blocks of 32 (GQA: two heads x 64
+    // rows; MHA: one head x 128 rows as before; four heads x 32 rows is the other legal value). Heads of one kv-head read the
+    // same K/V tiles and have the same causal extent: fewer waves idle through the last tiles of their workgroup (128-row
+    // blocks: 2 of every 8i + 8 wave-tile slots) and the per-tile barrier joins waves that did more nearly the same work.
     const int G = p.H / p.KVH;
-    const int per_unit = G * p.num_q_blocks;
+    const int hpw = p.hpw, hgroups = G / hpw;
+    const int rows_wg = (4 / hpw) * 32;
+    const int per_unit = hgroups * p.num_q_blocks;
     const int id = blockIdx.x;
     const int xcd = id & 7;
     const int j = id >> 3;
     const int unit = xcd + 8 * (j / per_unit);
     if (unit >= p.num_seqs * p.KVH) return;
     const int inner = j % per_unit;
-    const int g = inner % G;
-    const int qb = p.num_q_blocks - 1 - inner / G; // longest rows first
+    const int qb = p.num_q_blocks - 1 - inner / hgroups; // longest rows first
     const int seq = unit / p.KVH;
     const int kvh = unit % p.KVH;
-    const int head = kvh * G + g;
 
     const int start = p.cu_seqlens[seq];
     const int len = p.cu_seqlens[seq + 1] - start;
-    const int q0 = qb * kBQ;
+    const int q0 = qb * rows_wg;
     if (q0 >= len) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int head = kvh * G + (inner % hgroups) * hpw + wave % hpw;
     const int l32 = lane & 31;
     const int hf = lane >> 5;
-    const int q0w = q0 + wave * 32;
+    const int q0w = q0 + (wave / hpw) * 32;
     const int qrow = q0w + l32;
     const float c = p.scale_log2e;
 
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_dma_kernel(PrefillParams 
         }
     };
 
-    const int kv_end = min(len, q0 + kBQ);
+    const int kv_end = min(len, q0 + rows_wg);
     const int ntiles = (kv_end + kBK - 1) / kBK;
     const int last_rows = kv_end - (ntiles - 1) * kBK > 0 ? min(kBK, len - (ntiles - 1) * kBK) : kBK;
 
@@ -636,18 +642,33 @@ extern "C" int swl_prefill_attn_varlen(void *o, const void *q, const void *k, co
     p.k_tok_stride = k_tok_stride;
     p.v_tok_stride = v_tok_stride;
     p.o_tok_stride = o_tok_stride;
+    p.hpw = 1;
     const int64_t units = static_cast<int64_t>(num_prefill_seqs) * num_kv_heads;
     const int64_t units_padded = (units + 7) / 8 * 8;
-    const int64_t nblocks = units_padded * (num_q_heads / num_kv_heads) * p.num_q_blocks;
+    const int G = num_q_heads / num_kv_heads;
+    int64_t nblocks = units_padded * G * p.num_q_blocks;
     if (nblocks > 0x7fffffffLL) return SWL_ERR_UNSUPPORTED;
-    const dim3 grid(static_cast<unsigned>(nblocks));
+    dim3 grid(static_cast<unsigned>(nblocks));
     hipStream_t s = static_cast<hipStream_t>(stream);
     // A/B switch for measurements: SWL_PREFILL_ATTN=v1 runs the register-staged kernel at head_dim 128 as well
     static const bool use_v1 = [] { const char *e = getenv("SWL_PREFILL_ATTN"); return e && e[0] == 'v' && e[1] == '1'; }();
     const bool fits32 = static_cast<int64_t>(swl::kBK) * (k_tok_stride > v_tok_stride ? k_tok_stride : v_tok_stride) * 2 + 4096 < (1ll << 32);
     SWL_DISPATCH_DTYPE(dtype, T, {
-        if (head_dim == 128 && !use_v1 && fits32)
+        if (head_dim == 128 && !use_v1 && fits32) {
+            // heads of a kv-head side by side in a workgroup (see the kernel); A/B: SWL_PREFILL_HPW=1 keeps 128-row blocks
+            static const int forced_hpw = [] { const char *e = getenv("SWL_PREFILL_HPW"); return e ? atoi(e) : 0; }();
+            // measured (tools/gpu_prefill_hpw_ab.sh, profiles/r06b_prefill_attn_heads_per_group_ab.jsonl; GQA 32 / 8): two heads
+            // x 64 rows +1.3 % at 32 x 1024, +4.3 % on ragged lengths, +0.6 % at 8 x 4096 over one head x 128 rows; four heads
+            // x 32 rows +1.0 / +2.5 / +0.5 %
+            p.hpw = G % 2 == 0 ? 2 : 1;
+            if (forced_hpw == 1 || forced_hpw == 2 || forced_hpw == 4) p.hpw = G % forced_hpw == 0 ? forced_hpw : p.hpw;
+            const int rows_wg = (4 / p.hpw) * 32;
+            p.num_q_blocks = (max_prefill_len + rows_wg - 1) / rows_wg;
+            nblocks = units_padded * (G / p.hpw) * p.num_q_blocks;
+            if (nblocks > 0x7fffffffLL) return SWL_ERR_UNSUPPORTED;
+            grid = dim3(static_cast<unsigned>(nblocks));
             hipLaunchKernelGGL((swl::prefill_attn_dma_kernel<T>), grid, dim3(256), 0, s, p);
+        }
         else if (head_dim == 128)
             hipLaunchKernelGGL((swl::prefill_attn_kernel<T, 128>), grid, dim3(256), 0, s, p);
         else if (head_dim == 64)

@@ -418,7 +418,7 @@ def gemm_roofline(model, batch, iters):
     e = model.dtype.itemsize
     alg_bytes = 2 * I * K * e + M * K * e + M * I * e
     gbs = alg_bytes / (us * 1e-6) / 1e9
-    pmc_name = ("r05_gemm_silu_nf_pmc.json" if nf else "r04_gemm_silu_packed_pmc.json") if packed else "r01e_gemm_silu_pmc.json"
+    pmc_name = ("r06b_gemm_silu_nf_pmc.json" if nf else "r04_gemm_silu_packed_pmc.json") if packed else "r01e_gemm_silu_pmc.json"
     traffic, src = _pmc_traffic(pmc_name, alg_bytes, (I, K) == (14336, 4096) and model.dtype == torch.bfloat16)
     return dict(bound="hbm", kernel="%s (gemm_skinny_ring_kernel<SiluGate%s%s>: up/gate projection + SiLU-gate)" % (
                     fn, ", packed W" if packed else "", ", norm on the fly" if nf else ""),

@@ -139,7 +139,7 @@ def build_model(args, cfg, min_blocks, batch, max_len, hip_graph, max_tokens=0):
     with open(os.path.join(path, "config.json"), "w", encoding="utf-8") as f:
         json.dump(cfg, f)
     ec = EngineConfig(model_path=path, use_dummy=True, block_size=16, gpu_mem_utilization=0.97,
-                      num_cpu_blocks=0, max_seqs_in_block_table=max(64, batch) + 64,
+                      num_cpu_blocks=int(getattr(args, "num_cpu_blocks", 0) or 0), max_seqs_in_block_table=max(64, batch) + 64,
                       max_blocks_per_seq=max(FILLER_BLOCKS_PER_SEQ, max_len // 16 + 8),
                       max_batch_size=batch, max_tokens_in_batch=max_tokens or batch * min(max_len, 8192),
                       dtype=args.dtype, fuse_qkv=args.fuse_qkv, use_hip_graph=hip_graph,

@@ -44,6 +44,7 @@ class Engine:
         self.tokenization_engine = None
         self.untokenized_raw_requests: List[Tuple[Request, RawRequest]] = []
         self.num_forwards = 0
+        self.num_swapped_out = self.num_swapped_in = 0     # sequences moved to / from the host swap pool so far
         # asyncio thread -> model thread: lists of servable requests (the scheduler is touched by the model thread only)
         self._inbox: "queue.SimpleQueue[List[Request]]" = queue.SimpleQueue()
         # model thread only: (request, token, finished) of the last step, not fanned out yet
@@ -196,8 +197,10 @@ class Engine:
                 return False
         if swap_out:
             self.model.swap_out_seqs([r.request_id for r in swap_out])
+            self.num_swapped_out += len(swap_out)
         if swap_in:
             self.model.swap_in_seqs([r.request_id for r in swap_in])
+            self.num_swapped_in += len(swap_in)
         if batch:
             # prefill sequences first (the scheduler orders them so), their whole prompt; decoding ones
             # bring their last token and their length INCLUDING it

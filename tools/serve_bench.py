@@ -31,6 +31,7 @@ def parse():
     ap.add_argument("--rate", type=float, default=0.0, help="Poisson arrival rate (req/s); 0 = all at once")
     ap.add_argument("--modes", default="plain,piggyback")
     ap.add_argument("--kv-blocks", type=int, default=0, help="KV pool size in blocks (0 = profile_num_blocks at 0.97)")
+    ap.add_argument("--cpu-blocks", type=int, default=0, help="host swap pool in blocks (with a small --kv-blocks: swapping under load)")
     ap.add_argument("--sweep", default="", help="comma-separated Poisson rates (req/s): the online sweep to the knee")
     ap.add_argument("--sweep-seconds", type=float, default=10.0, help="seconds of arrivals per rate of the sweep")
     ap.add_argument("--lengths", default="fixed", choices=["fixed", "sharegpt"],
@@ -87,6 +88,7 @@ async def run(model, a, piggyback, eng=None, seed=7):
         if a.rate > 0:
             t += rng.expovariate(a.rate)
     caps0, fwd0, cap_s0 = getattr(model, "graph_captures", 0), eng.num_forwards, getattr(model, "graph_capture_s", 0.0)
+    so0, si0 = eng.num_swapped_out, eng.num_swapped_in
     t0 = time.perf_counter()
     await asyncio.gather(*(one(p, gl, d) for p, (_, gl), d in zip(prompts, lens, delays)))
     dt = time.perf_counter() - t0
@@ -107,6 +109,7 @@ async def run(model, a, piggyback, eng=None, seed=7):
             "ttft_ms_p99": round(ttft[int(len(ttft) * 0.99)] * 1e3, 1),
             # every capture = one eager warm-up forward + one capture (worker/model.py: _forward_decode_graph); keyed on batch
             # BUCKETS and split-geometry buckets since r05
+            "seqs_swapped_out": eng.num_swapped_out - so0, "seqs_swapped_in": eng.num_swapped_in - si0,
             "graph_captures": caps, "graph_captures_per_1000_forwards": round(1000.0 * caps / fwds, 2),
             "graph_capture_s": round(getattr(model, "graph_capture_s", 0.0) - cap_s0, 3),
             "graphs_cached": len(getattr(model, "_decode_graphs", {}) or {}),
@@ -162,9 +165,10 @@ def main():
     # Llama-3-8B on a 288 GB MI355X) unless --kv-blocks says otherwise; no filler sequences: the engine hands out sequence ids
     ns = argparse.Namespace(batch=2 * a.max_batch, prompt_len=a.prompt_len, steps=a.gen_len, warmup=0, dtype=a.dtype,
                             fuse_qkv=True, no_hip_graph=False, skinny_gemm=True, splitk_fusion=True,
-                            kv_blocks=a.kv_blocks, kv_placement="bottom")
+                            kv_blocks=a.kv_blocks, kv_placement="bottom", num_cpu_blocks=a.cpu_blocks)
     blocks_per_seq = (a.prompt_len + a.gen_len + 16) // 16
-    model = bench.build_model(ns, cfg, int(a.max_batch * blocks_per_seq * 1.1) + 8, 2 * a.max_batch,
+    min_blocks = int(a.max_batch * blocks_per_seq * 1.1) + 8 if not a.kv_blocks else min(a.kv_blocks, blocks_per_seq + 8)
+    model = bench.build_model(ns, cfg, min_blocks, 2 * a.max_batch,
                               a.prompt_len + a.gen_len + 16, True)
     # scheduler limits (the block table was built for 2 x max_batch ids: running + swapped-out requests)
     model.engine_config.max_tokens_in_batch = a.max_tokens

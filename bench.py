@@ -888,7 +888,8 @@ def _run(args):
                                                      kv_placement="bottom"))
                 result["configs2_fp16"] = side_run(f16_args, "llama3-8b", B, S + GEN // 2, 24, 6,
                                                    f"llama3-8b float16 decode-only, batch {B} at context ~{S + GEN // 2}: the reference's "
-                                                   f"precision and rounding points (no deferred norm: 7 launches per layer)")
+                                                   f"precision AND rounding points — the exact norm on the fly of r06c: o_proj adds itself into the residual and "
+                                                   f"leaves the rows' sums of squares, the SiLU-gate GEMM stages round(r * rstd * w); 6 launches per layer")
         except Exception as exc:     # noqa: BLE001 — a side measurement must never take the bench line down
             print(f"[bench] float16 side run failed ({type(exc).__name__}: {exc})", file=sys.stderr)
         try:

@@ -429,6 +429,26 @@ int swl_gemm_skinny_packed_silu_gate_nf(void *out, const void *x, const void *no
                                         const void *w_up_gate_packed, int32_t M, int32_t I, int32_t K,
                                         int64_t x_row_stride, int64_t out_row_stride, int32_t dtype, swl_stream_t stream);
 
+/* ---- the same path with the reference's rounding points (r06c: float16 AND bfloat16) -----------------------------------------
+ * The deferred norm of the `_nf` entries rounds round(r * w) and applies the 1/rms after the projection — bfloat16 only
+ * (DESIGN.md section 4.5). Here the norm is EXACT: fused_add_rmsnorm's arithmetic (reference rmsnorm.py:54-64 at
+ * layers/transformer_layer.py:46,120: the sum rounded and stored, the sums of squares and the 1/rms in fp32, ONE rounding of
+ * r * rstd * w), split over the two launches that are there anyway:
+ *   swl_gemm_rows_add_ssq: swl_gemm_rows_add + ssq_out[M][N / 16] (fp32) = per (token, 16-column tile) sums of squares of the
+ *     updated residual rows (the workgroup that finishes a tile has its values in registers);
+ *   swl_gemm_skinny_packed_silu_gate_nx / swl_gemm_skinny_packed_partial_nx: the consuming projections add the ssq_parts
+ *     (= hidden / 16, % 64 == 0) partials of every row in a fixed order before their first tile and stage
+ *     round(r * rstd * norm_w); outputs as swl_gemm_skinny_packed_silu_gate / swl_gemm_skinny_packed_partial (nothing
+ *     pending: the slabs go to swl_paged_attn_decode_qkv as they are). */
+int swl_gemm_rows_add_ssq(void *residual, float *ssq_out, const void *x, const void *w_packed, int32_t M, int32_t N, int32_t K,
+                          int64_t x_row_stride, int32_t dtype, swl_stream_t stream);
+int swl_gemm_skinny_packed_silu_gate_nx(void *out, const void *x, const void *norm_w, float eps, const float *ssq_in,
+                                        int32_t ssq_parts, const void *w_up_gate_packed, int32_t M, int32_t I, int32_t K,
+                                        int64_t x_row_stride, int64_t out_row_stride, int32_t dtype, swl_stream_t stream);
+int swl_gemm_skinny_packed_partial_nx(float *slabs, size_t slabs_bytes, const void *x, const void *norm_w, float eps,
+                                      const float *ssq_in, int32_t ssq_parts, const void *w_packed, int32_t M, int32_t N,
+                                      int32_t K, int64_t x_row_stride, int32_t k_splits, int32_t dtype, swl_stream_t stream);
+
 /* ---- the transformer stack of a one-sequence decode step as ONE persistent launch (csrc/decode_engine.hip) ----------------
  * reference: the layer loop of LlamaModel._forward (swiftllm/worker/model.py:228-249) over
  * LlamaTransformerLayer.forward (swiftllm/worker/layers/transformer_layer.py:31-130) for ONE decoding sequence: embedding row

@@ -86,6 +86,9 @@ SIGNATURES = {
     "swl_gemm_rows_add": [_P, _P, _P, _I32, _I32, _I32, _I64, _I32, _P],
     "swl_gemm_skinny_packed_partial_nf": [_P, ctypes.c_size_t, _P, _P, _P, _P, _I32, _I32, _I32, _I64, _I32, _I32, _P],
     "swl_gemm_skinny_packed_silu_gate_nf": [_P, _P, _P, _F32, _P, _I32, _I32, _I32, _I64, _I64, _I32, _P],
+    "swl_gemm_rows_add_ssq": [_P, _P, _P, _P, _I32, _I32, _I32, _I64, _I32, _P],
+    "swl_gemm_skinny_packed_silu_gate_nx": [_P, _P, _P, _F32, _P, _I32, _P, _I32, _I32, _I32, _I64, _I64, _I32, _P],
+    "swl_gemm_skinny_packed_partial_nx": [_P, ctypes.c_size_t, _P, _P, _F32, _P, _I32, _P, _I32, _I32, _I32, _I64, _I32, _I32, _P],
     "swl_decode_engine_reset": [_P, ctypes.c_size_t, _P],
     "swl_decode_engine_step": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P, _P, _I32, _I32,
                                _I32, _I32, _I32, _I32, _I32, _F32, _F32, _I32, _I32, _P],

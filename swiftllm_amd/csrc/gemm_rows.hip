@@ -60,6 +60,9 @@ struct RowsArgs {
     void *residual;
     int M, N, K;
     int64_t x_stride;
+    // optional (r06c): ssq_out[M][N / 16] = sum of squares of the NEW residual values of (token, 16-column tile) — what an
+    // EXACT rmsnorm of the updated rows needs before the next projection can stage them (swl_gemm_skinny_packed_*_nx)
+    float *ssq_out;
 };
 
 // NCH > 0: the chunk count per wave is a compile-time constant <= kRowsRing — every load is issued up front, straight-line
@@ -193,6 +196,11 @@ __global__ __launch_bounds__(kRowsWaves * 64, 2) void gemm_rows_kernel(RowsArgs 
     // splitk_add_scale_kernel's arithmetic (rmsnorm.hip) on this thread's element
     const T xn = add_t<T>(to_t<T>(s), rv); // the projection is rounded, then the sum (rmsnorm.py:54-57)
     if (e_ok) *res_p = xn;
+    if (a.ssq_out != nullptr) {             // (wave-uniform) the 16 column lanes of a token: one DPP row reduction
+        const float v = e_ok ? to_f(xn) : 0.f;
+        const float t = group_allreduce_sum<16>(v * v);
+        if (e_ok && en == 0) a.ssq_out[static_cast<int64_t>(et) * (N / kRowsTile) + tile16] = t;
+    }
 }
 
 static bool rows_shape_ok(int M, int N, int K) {
@@ -223,8 +231,23 @@ static bool rows_x_through_lds(int M) {
 
 extern "C" int swl_gemm_rows_supported(int32_t M, int32_t N, int32_t K) { return swl::rows_shape_ok(M, N, K) ? 1 : 0; }
 
+static int rows_add_impl(void *residual, float *ssq_out, const void *x, const void *w_packed, int32_t M, int32_t N, int32_t K,
+                         int64_t x_row_stride, int32_t dtype, swl_stream_t stream);
+
 extern "C" int swl_gemm_rows_add(void *residual, const void *x, const void *w_packed, int32_t M, int32_t N, int32_t K,
                                  int64_t x_row_stride, int32_t dtype, swl_stream_t stream) {
+    return rows_add_impl(residual, nullptr, x, w_packed, M, N, K, x_row_stride, dtype, stream);
+}
+
+/* swl_gemm_rows_add + ssq_out[M][N / 16] (fp32): per (token, 16-column tile) the sum of squares of the updated residual. */
+extern "C" int swl_gemm_rows_add_ssq(void *residual, float *ssq_out, const void *x, const void *w_packed, int32_t M, int32_t N,
+                                     int32_t K, int64_t x_row_stride, int32_t dtype, swl_stream_t stream) {
+    if (M > 0 && (!ssq_out || (reinterpret_cast<uintptr_t>(ssq_out) & 3u))) return SWL_ERR_BAD_ARG;
+    return rows_add_impl(residual, ssq_out, x, w_packed, M, N, K, x_row_stride, dtype, stream);
+}
+
+static int rows_add_impl(void *residual, float *ssq_out, const void *x, const void *w_packed, int32_t M, int32_t N, int32_t K,
+                         int64_t x_row_stride, int32_t dtype, swl_stream_t stream) {
     if (M < 0 || N <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
     if (M == 0) return SWL_OK;
     if (!residual || !x || !w_packed) return SWL_ERR_BAD_ARG;
@@ -233,7 +256,7 @@ extern "C" int swl_gemm_rows_add(void *residual, const void *x, const void *w_pa
     if (!swl::aligned16(x) || !swl::aligned16(w_packed) || (reinterpret_cast<uintptr_t>(residual) & 1u)) return SWL_ERR_BAD_ARG;
     swl::RowsArgs a = {};
     a.x = x; a.wp = w_packed; a.residual = residual;
-    a.M = M; a.N = N; a.K = K; a.x_stride = x_row_stride;
+    a.M = M; a.N = N; a.K = K; a.x_stride = x_row_stride; a.ssq_out = ssq_out;
     SWL_DISPATCH_DTYPE(dtype, T, {
         const hipStream_t s = static_cast<hipStream_t>(stream);
         if (swl::rows_x_through_lds(M))

@@ -238,7 +238,12 @@ constexpr int kRing = 3;
 // behind: no consumer launch computed round(r * norm_w) or the sums of squares). The norm-weight chunk of a K-tile rides
 // with the tile's x loads, the staging pass multiplies and rounds (the bits of splitk_add_scale_kernel) and accumulates
 // sum r^2 per row in fp32 — every workgroup redundantly, it sees all of x anyway.
-template <typename T, int MODE, bool PACKED = false, int RD = kRing, int NWV = kGemmWaves, bool NF = false>
+// NX (with NF; r06c): the EXACT norm on the fly — x is the raw residual stream r as in NF, but the rows' sums of squares are
+// already known (fuse.ssq_in[M][ssq_parts]: the per-tile partials swl_gemm_rows_add_ssq left behind), so the workgroup
+// first adds them up in a fixed order, and the staging pass writes round(r * rstd * w) — the reference's one rounding of the
+// normalised activation (rmsnorm.py:57-64; rmsnorm.hip's expression) — in float16 as in bfloat16. Nothing is deferred: the
+// epilogues see rs = 1.
+template <typename T, int MODE, bool PACKED = false, int RD = kRing, int NWV = kGemmWaves, bool NF = false, bool NX = false>
 // 2 waves per SIMD: the ring holds RD x 8 KiB of W per wave in registers (~220 VGPRs at RD = 3); the two-wave SiLU-gate
 // form stages twice the x rows per wave and runs one wave per SIMD (two workgroups per CU)
 __global__ __launch_bounds__(NWV * 64, NWV == 2 ? 1 : 2) void gemm_skinny_ring_kernel(
@@ -249,6 +254,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 2 ? 1 : 2) void gemm_skinny_ring_k
                   "3 waves: packed partial only; 2 waves: packed SiLU-gate only");
     constexpr int HWV = NWV / 2;         // SiLU-gate: waves [0, HWV) own `up` tiles, [HWV, NWV) the matching `gate` tiles
     static_assert(!NF || (PACKED && MODE != kGemmDirect), "norm on the fly: packed SiLU-gate / partial only");
+    static_assert(!NX || NF, "the exact norm on the fly is a mode of NF");
     constexpr int D = RD;
     constexpr int XL = (8 + NWV - 1) / NWV; // x row-groups (4 rows each) a wave stages per tile
     constexpr int XROWS = 4 * XL * NWV;      // 32, or 36 with the dummy group of the 3-wave variant
@@ -306,6 +312,31 @@ __global__ __launch_bounds__(NWV * 64, NWV == 2 ? 1 : 2) void gemm_skinny_ring_k
         for (int p2 = 0; p2 < 8; ++p2) ssv[p2] = p2 < fuse.ssq_parts ? fuse.ssq_in[p2 * M + m] : 0.f;
     }
 
+    // NX: the partial sums of squares are the OLDEST requests of the workgroup (they come back before any tile)
+    float nx_part[NX ? 2 : 1][8];
+    if constexpr (NX) {
+        // 32 tokens x 8 pieces of ssq_parts / 8 consecutive partials each (ssq_parts % 8 == 0): item = token * 8 + piece
+        const int per = fuse.ssq_parts >> 3;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int item = static_cast<int>(threadIdx.x) + it * NWV * 64;
+            const int tok = min(item >> 3, M - 1), piece = item & 7;
+            const float *src = fuse.ssq_in + static_cast<int64_t>(tok) * fuse.ssq_parts + piece * per;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) nx_part[it][e] = 0.f;
+            if (item < 256) {
+                for (int c = 0; c < per; c += 8) {          // (per % 8 == 0 is checked by the host: 32-byte runs)
+                    const float4_t u0 = *reinterpret_cast<const float4_t *>(src + c);
+                    const float4_t u1 = *reinterpret_cast<const float4_t *>(src + c + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        nx_part[it][e] += u0[e];
+                        nx_part[it][4 + e] += u1[e];
+                    }
+                }
+            }
+        }
+    }
     vec8_t<T> wr[D][8], xr[D][XL];
     vec8_t<T> wn[NF ? D : 1];           // NF: the norm-weight chunk of the tile (same 8 columns for every row of the lane)
     float ssq_acc[NF ? XL : 1];
@@ -326,7 +357,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 2 ? 1 : 2) void gemm_skinny_ring_k
     {                                                                                                \
         _Pragma("unroll") for (int q_ = 0; q_ < XL; ++q_) {                                          \
             vec8_t<T> xv_ = xr[slot][q_];                                                            \
-            if constexpr (NF) {                                                                      \
+            if constexpr (NX) {                                                                      \
+                _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_)                                     \
+                    xv_[j_] = to_t<T>(to_f(xv_[j_]) * rstd_q[q_] * to_f(wn[slot][j_]));              \
+            } else if constexpr (NF) {                                                               \
                 _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                   \
                     const float v_ = to_f(xv_[j_]);                                                  \
                     ssq_acc[q_] = fmaf(v_, v_, ssq_acc[q_]);                                         \
@@ -358,6 +392,28 @@ __global__ __launch_bounds__(NWV * 64, NWV == 2 ? 1 : 2) void gemm_skinny_ring_k
 #pragma unroll
     for (int d = 0; d < D - 1; ++d)
         if (d < nkt) SWL_ISSUE(d, d);
+    float rstd_q[NX ? XL : 1];
+    if constexpr (NX) {
+        // pieces -> LDS (the second x buffer is idle until tile 1 is staged), 8 pieces per token in order, 1/rms per row
+        float *scr = reinterpret_cast<float *>(&lds[1][0]);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int item = static_cast<int>(threadIdx.x) + it * NWV * 64;
+            if (item < 256)
+                scr[item] = ((nx_part[it][0] + nx_part[it][1]) + (nx_part[it][2] + nx_part[it][3])) +
+                            ((nx_part[it][4] + nx_part[it][5]) + (nx_part[it][6] + nx_part[it][7]));
+        }
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            const float *pp = scr + threadIdx.x * 8;
+            const float ss = ((pp[0] + pp[1]) + (pp[2] + pp[3])) + ((pp[4] + pp[5]) + (pp[6] + pp[7]));
+            ssq_row[threadIdx.x] = 1.0f / sqrtf(ss / static_cast<float>(K) + fuse.eps);     // rmsnorm.hip's formula
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < XL; ++q) rstd_q[q] = ssq_row[min(4 * (wave * XL + q) + rsub, 31)];
+        __syncthreads();        // (scr is the x buffer of tile 1: nobody may still be reading it when tile 1 is staged)
+    }
     SWL_STAGE_X(0, 0, 0);
     __syncthreads();
     int kt = 0;
@@ -394,7 +450,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 2 ? 1 : 2) void gemm_skinny_ring_k
 #undef SWL_PROCESS
     mfma_results_ready<8>(acc); // acc comes straight out of the K loop (swl_common.h)
     if constexpr (PACKED) {
-        if constexpr (NF) { // the 16 chunk lanes of a row hold its sum of squares in pieces: DPP row reduction -> LDS
+        if constexpr (NF && !NX) { // the 16 chunk lanes of a row hold its sum of squares in pieces: DPP row reduction -> LDS
 #pragma unroll
             for (int q = 0; q < XL; ++q) {
                 const float t = group_allreduce_sum<16>(ssq_acc[q]);
@@ -404,11 +460,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 2 ? 1 : 2) void gemm_skinny_ring_k
         // no W tiles in LDS: the SiLU-gate exchange (32 x 40 elements per wave) reuses the x buffers once every
         // wave is done reading them
         if constexpr (MODE == kGemmSiluGate || NF) __syncthreads();
-        if constexpr (NF && MODE == kGemmPartial) {
+        if constexpr (NF && !NX && MODE == kGemmPartial) {
             if (blockIdx.x == 0 && wave == 0 && lane < M) fuse.ssq_out[ksplit * M + lane] = ssq_row[lane];
         }
         float rs = 1.0f;
-        if constexpr (NF && MODE == kGemmSiluGate) {
+        if constexpr (NX) {
+            // (already normalised: nothing pending)
+        } else if constexpr (NF && MODE == kGemmSiluGate) {
             rs = 1.0f / sqrtf(ssq_row[min(lane & 31, M - 1)] / static_cast<float>(K) + fuse.eps);
         } else if (row_scaled) {
             const float ss = ((ssv[0] + ssv[1]) + (ssv[2] + ssv[3])) + ((ssv[4] + ssv[5]) + (ssv[6] + ssv[7]));
@@ -890,6 +948,83 @@ extern "C" int swl_gemm_skinny_packed_silu_gate_nf(void *out, const void *x, con
                                grid, dim3(swl::kGemmWaves * 64), 0, s, out, static_cast<const T *>(x),
                                static_cast<const T *>(w_up_gate_packed), M, I, K, K, x_row_stride, out_row_stride, f);
     });
+    return swl::check_launch();
+}
+
+/* ---- the EXACT norm on the fly (r06c): the reference's rounding points on the row-owned decode path, float16 included --------
+ * x = the raw residual rows r[M, K] that swl_gemm_rows_add_ssq left behind, ssq_in[M][ssq_parts] its per-tile sums of squares
+ * (ssq_parts = K / 16 for a row-owned projection; % 64 == 0). The workgroup adds the partials in a fixed order and stages
+ * round(r * rstd * norm_w), rstd = 1/sqrt(sum / K + eps) — rmsnorm.hip's expression, reference rmsnorm.py:57-64 — so the
+ * products are those of rmsnorm + projection up to the summation order of the sums of squares. */
+extern "C" int swl_gemm_skinny_packed_silu_gate_nx(void *out, const void *x, const void *norm_w, float eps, const float *ssq_in,
+                                                   int32_t ssq_parts, const void *w_up_gate_packed, int32_t M, int32_t I,
+                                                   int32_t K, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype,
+                                                   swl_stream_t stream) {
+    if (M < 0 || I <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
+    if (M == 0) return SWL_OK;
+    if (!out || !x || !norm_w || !w_up_gate_packed || !ssq_in) return SWL_ERR_BAD_ARG;
+    if (M > 32 || (I & 31) || (K & (swl::kKT - 1)) || ssq_parts <= 0 || (ssq_parts & 63) || !swl::use_ring(K)) return SWL_ERR_UNSUPPORTED;
+    if (x_row_stride < K || out_row_stride < I || (x_row_stride & 7) || (out_row_stride & 3)) return SWL_ERR_BAD_ARG;
+    if (!swl::aligned16(x) || !swl::aligned16(w_up_gate_packed) || !swl::aligned16(norm_w) || !swl::aligned16(ssq_in) ||
+        (reinterpret_cast<uintptr_t>(out) & 7u))
+        return SWL_ERR_BAD_ARG;
+    swl::GemmExtra f{};
+    f.norm_w = norm_w;
+    f.eps = eps;
+    f.ssq_in = ssq_in;
+    f.ssq_parts = ssq_parts;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    SWL_DISPATCH_DTYPE(dtype, T, {
+        if (M <= 8)     // (two-wave workgroups: see swl_gemm_skinny_packed_silu_gate_nf)
+            hipLaunchKernelGGL((swl::gemm_skinny_ring_kernel<T, swl::kGemmSiluGate, true, 3, 2, true, true>), dim3(I / 32, 1),
+                               dim3(128), 0, s, out, static_cast<const T *>(x), static_cast<const T *>(w_up_gate_packed), M,
+                               I, K, K, x_row_stride, out_row_stride, f);
+        else
+            hipLaunchKernelGGL((swl::gemm_skinny_ring_kernel<T, swl::kGemmSiluGate, true, 3, swl::kGemmWaves, true, true>),
+                               dim3((I / 32 + 1) / 2, 1), dim3(swl::kGemmWaves * 64), 0, s, out, static_cast<const T *>(x),
+                               static_cast<const T *>(w_up_gate_packed), M, I, K, K, x_row_stride, out_row_stride, f);
+    });
+    return swl::check_launch();
+}
+
+/* slabs[k_splits][M][N] of round(r * rstd * norm_w) . W^T (nothing pending: swl_paged_attn_decode_qkv takes them as they are).
+ * Even K splits of whole 128-column tiles; N / 32 % 3 == 0 runs three-wave workgroups as swl_gemm_skinny_packed_partial_nf. */
+extern "C" int swl_gemm_skinny_packed_partial_nx(float *slabs, size_t slabs_bytes, const void *x, const void *norm_w, float eps,
+                                                 const float *ssq_in, int32_t ssq_parts, const void *w_packed, int32_t M,
+                                                 int32_t N, int32_t K, int64_t x_row_stride, int32_t k_splits, int32_t dtype,
+                                                 swl_stream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0) return SWL_ERR_BAD_ARG;
+    if (M == 0) return SWL_OK;
+    if (!slabs || !x || !norm_w || !w_packed || !ssq_in || k_splits < 1 || k_splits > 16) return SWL_ERR_BAD_ARG;
+    if (M > 32 || (N & 31) || (K & (swl::kKT - 1)) || K % (swl::kKT * k_splits) || ssq_parts <= 0 || (ssq_parts & 63))
+        return SWL_ERR_UNSUPPORTED;
+    if (x_row_stride < K || (x_row_stride & 7)) return SWL_ERR_BAD_ARG;
+    if (!swl::aligned16(x) || !swl::aligned16(w_packed) || !swl::aligned16(norm_w) || !swl::aligned16(slabs) || !swl::aligned16(ssq_in))
+        return SWL_ERR_BAD_ARG;
+    if (slabs_bytes < static_cast<size_t>(k_splits) * M * N * sizeof(float)) return SWL_ERR_BAD_ARG;
+    swl::GemmExtra f{};
+    f.norm_w = norm_w;
+    f.eps = eps;
+    f.ssq_in = ssq_in;
+    f.ssq_parts = ssq_parts;
+    const int kc = K / k_splits;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t n64 = N;
+#define SWL_NX_PARTIAL(RD_, NWV_)                                                                                        \
+    hipLaunchKernelGGL((swl::gemm_skinny_ring_kernel<T, swl::kGemmPartial, true, RD_, NWV_, true, true>), grid,    \
+                       dim3(NWV_ * 64), 0, s, static_cast<void *>(slabs), static_cast<const T *>(x),                     \
+                       static_cast<const T *>(w_packed), M, N, K, kc, x_row_stride, n64, f)
+    SWL_DISPATCH_DTYPE(dtype, T, {
+        if (swl::prefer_three_waves(N, k_splits)) {
+            const dim3 grid(N / 32 / 3, k_splits);
+            SWL_NX_PARTIAL(2, 3);
+        } else {
+            const dim3 grid((N / 32 + swl::kGemmWaves - 1) / swl::kGemmWaves, k_splits);
+            if (swl::use_ring(kc)) SWL_NX_PARTIAL(3, 4);
+            else SWL_NX_PARTIAL(2, 4);
+        }
+    });
+#undef SWL_NX_PARTIAL
     return swl::check_launch();
 }
 

@@ -33,8 +33,9 @@ class EngineConfig:
     # ---- MI355X additions (all optional) -------------------------------------------------------
     # Storage/compute dtype of weights, activations and the KV pool. The reference hard-codes
     # float16 (model.py:70,147); bfloat16 is the headline precision on MI355X. NOTE: float16 keeps the reference's
-    # rounding points everywhere, so the two bfloat16-only decode fast paths below (defer_rmsnorm, tiny_decode_batches)
-    # are off for it: ~1.5 us per layer slower at batch 32, 7 instead of 5 launches per layer at batch <= 2.
+    # rounding points everywhere, so the bfloat16-only deferred norm (defer_rmsnorm, tiny_decode_batches) is off for it;
+    # since r06c its row-owned projections run the EXACT norm on the fly instead (rows_decode: the same 5-6 launches per
+    # layer with fused_add_rmsnorm's arithmetic — 3.95 vs 4.10 ms per step at batch 32, 3.11 vs 3.25 at batch 1).
     dtype: str = "float16"
     # One [h + 2*KVH*D, h] GEMM instead of three (the reference left this commented out,
     # weight.py:131). fuse_qkv=False + use_skinny_gemm=False reproduces the reference's exact BLAS calls.
@@ -66,10 +67,11 @@ class EngineConfig:
         # batches of <= 2 sequences: the qkv and up/gate projections sum the previous projection's slabs themselves
         # (csrc/gemm_tiny.hip), 5 launches per layer instead of 7
         tiny_decode_batches=True,
-        # decode batches of <= 32 sequences, bfloat16: o_proj — and down_proj up to 16 sequences — finish their rows INSIDE the
+        # decode batches of <= 32 sequences: o_proj — and down_proj up to 16 sequences — finish their rows INSIDE the
         # workgroup that owns them (csrc/gemm_rows.hip: K split across the 8 waves, residual add in the epilogue: no slabs,
         # no consumer launch), and the projection that follows applies the norm weight and the 1/rms itself while it stages
-        # the raw residual rows ("norm on the fly", gemm_skinny.hip NF): 6 launches per layer at batch 32, 5 up to batch 16
+        # the raw residual rows ("norm on the fly", gemm_skinny.hip NF: bfloat16, deferred 1/rms; NX: either dtype, the exact
+        # norm from the per-tile sums of squares the row-owned kernel leaves): 6 launches per layer at batch 32, 5 up to 16
         rows_decode=True,
         # ONE decoding sequence: the whole transformer stack of the step as one persistent launch (csrc/decode_engine.hip: a
         # loader wave per CU streams that CU's rows of every projection by LDS-DMA, three consumer waves compute, operator

@@ -341,11 +341,12 @@ def linear_silu_gate(a: torch.Tensor, w_up_gate: torch.Tensor, row_scale=None):
 class RawResidual:
     """What a layer hands to the next one when its down projection already added itself into the residual buffer
     (linear_rows_add): there is no activation tensor and no slabs — the residual rows ARE the layer output, and the next
-    projection normalises them on the fly (linear_splitk_nf)."""
-    __slots__ = ("shape", "dtype")
+    projection normalises them on the fly (linear_splitk_nf; with `ssq` — the rows' per-tile sums of squares — exactly:
+    linear_splitk_nx)."""
+    __slots__ = ("shape", "dtype", "ssq")
 
-    def __init__(self, residual: torch.Tensor):
-        self.shape, self.dtype = tuple(residual.shape), residual.dtype
+    def __init__(self, residual: torch.Tensor, ssq: torch.Tensor = None):
+        self.shape, self.dtype, self.ssq = tuple(residual.shape), residual.dtype, ssq
 
 
 def rows_add_ok(a: torch.Tensor, w: torch.Tensor, residual: torch.Tensor) -> bool:
@@ -358,12 +359,19 @@ def rows_add_ok(a: torch.Tensor, w: torch.Tensor, residual: torch.Tensor) -> boo
             and bool(_hip.load().swl_gemm_rows_supported(m, n, k)))
 
 
-def linear_rows_add(a: torch.Tensor, w: torch.Tensor, residual_io: torch.Tensor) -> torch.Tensor:
+def linear_rows_add(a: torch.Tensor, w: torch.Tensor, residual_io: torch.Tensor, with_ssq: bool = False):
     """residual_io += round(a @ w^T), in place, one launch: the workgroup that owns 16 rows of w for all of K finishes
-    them itself (csrc/gemm_rows.hip). Returns residual_io."""
+    them itself (csrc/gemm_rows.hip). Returns residual_io — or, `with_ssq`, the fp32 [tokens, out / 16] per-tile sums of
+    squares of the updated rows (what an exact norm on the fly needs: linear_silu_gate_nx / linear_splitk_nx)."""
     assert rows_add_ok(a, w, residual_io)
     m, k = a.shape
-    _hip.call("swl_gemm_rows_add", _hip.ptr(residual_io), _hip.ptr(a), _hip.ptr(_packed_of(w)), m, w.shape[0], k,
+    n = w.shape[0]
+    if with_ssq:
+        ssq = torch.empty((m, n // 16), dtype=torch.float32, device=a.device)
+        _hip.call("swl_gemm_rows_add_ssq", _hip.ptr(residual_io), _hip.ptr(ssq), _hip.ptr(a), _hip.ptr(_packed_of(w)), m, n, k,
+                  _row_stride(a), _hip.dtype_code(a.dtype), _hip.stream())
+        return ssq
+    _hip.call("swl_gemm_rows_add", _hip.ptr(residual_io), _hip.ptr(a), _hip.ptr(_packed_of(w)), m, n, k,
               _row_stride(a), _hip.dtype_code(a.dtype), _hip.stream())
     return residual_io
 
@@ -401,6 +409,44 @@ def linear_silu_gate_nf(r: torch.Tensor, norm_w: torch.Tensor, eps: float, w_up_
     out = torch.empty((m, inter), dtype=r.dtype, device=r.device)
     _hip.call("swl_gemm_skinny_packed_silu_gate_nf", _hip.ptr(out), _hip.ptr(r), _hip.ptr(norm_w), eps,
               _hip.ptr(_packed_of(w_up_gate)), m, inter, k, _row_stride(r), inter, _hip.dtype_code(r.dtype), _hip.stream())
+    return out
+
+
+def nx_ok(r: torch.Tensor, w: torch.Tensor, norm_w: torch.Tensor) -> bool:
+    """Can a projection stage the EXACTLY normalised rows itself from the raw residual and its per-tile sums of squares
+    (swl_gemm_skinny_packed_*_nx)? Packed weight, <= 32 tokens, hidden a multiple of 1024 (64 partials per piece), either
+    16-bit dtype — the reference's rounding points, so no dtype policy applies."""
+    return (_packed_of(w) is not None and _skinny_ok(r, w) and norm_w.dtype == r.dtype and norm_w.is_contiguous()
+            and norm_w.numel() == r.shape[1] and r.shape[1] % 1024 == 0 and r.shape[1] >= 1024)
+
+
+def linear_splitk_nx(r: torch.Tensor, norm_w: torch.Tensor, w: torch.Tensor, eps: float, ssq: torch.Tensor):
+    """linear_splitk(rmsnorm(r) * norm_w, w, always=True) from the raw residual rows and their per-tile sums of squares
+    (linear_rows_add(..., with_ssq=True)): SplitKPartials with nothing pending, or None when K has no even split."""
+    assert nx_ok(r, w, norm_w) and ssq.dtype == torch.float32 and ssq.shape == (r.shape[0], r.shape[1] // 16) and ssq.is_contiguous()
+    m, k = r.shape
+    n = w.shape[0]
+    ks = int(_hip.load().swl_gemm_skinny_packed_choose_splits(n, k))
+    if k % (128 * ks):
+        return None
+    ws = _workspace(r.device, ks * m * n * 4)
+    _hip.call("swl_gemm_skinny_packed_partial_nx", _hip.ptr(ws), ws.numel() * 4, _hip.ptr(r), _hip.ptr(norm_w), eps,
+              _hip.ptr(ssq), ssq.shape[1], _hip.ptr(_packed_of(w)), m, n, k, _row_stride(r), ks, _hip.dtype_code(r.dtype),
+              _hip.stream())
+    return SplitKPartials(ws, ks, m, n, r.dtype)
+
+
+def linear_silu_gate_nx(r: torch.Tensor, norm_w: torch.Tensor, eps: float, w_up_gate: torch.Tensor, ssq: torch.Tensor):
+    """silu_and_mul(rmsnorm(r) * norm_w @ up_gate^T)[:, :I] from the raw residual rows and their per-tile sums of squares: one
+    launch, the reference's one rounding of the normalised activation."""
+    assert nx_ok(r, w_up_gate, norm_w) and w_up_gate.shape[0] % 64 == 0
+    assert ssq.dtype == torch.float32 and ssq.shape == (r.shape[0], r.shape[1] // 16) and ssq.is_contiguous()
+    m, k = r.shape
+    inter = w_up_gate.shape[0] // 2
+    out = torch.empty((m, inter), dtype=r.dtype, device=r.device)
+    _hip.call("swl_gemm_skinny_packed_silu_gate_nx", _hip.ptr(out), _hip.ptr(r), _hip.ptr(norm_w), eps, _hip.ptr(ssq),
+              ssq.shape[1], _hip.ptr(_packed_of(w_up_gate)), m, inter, k, _row_stride(r), inter, _hip.dtype_code(r.dtype),
+              _hip.stream())
     return out
 
 

@@ -42,6 +42,7 @@ from ..kernels.linear import attn_partials_ok, linear_splitk_from_attn_partials
 from ..kernels.linear import (row_scaled_silu_gate_ok, alt_residual_like, linear_silu_gate_from_splitk,
                               linear_splitk_from_splitk, tiny_from_splitk_ok)
 from ..kernels.linear import RawResidual, linear_rows_add, linear_silu_gate_nf, linear_splitk_nf, nf_ok, rows_add_ok
+from ..kernels.linear import linear_silu_gate_nx, linear_splitk_nx, nx_ok
 from ..kernels.rmsnorm import RowScalePending
 from ..kernels.rmsnorm import (add_scale_from_splitk, deferred_norm_ok, fused_add_rmsnorm_inplace,
                                fused_add_rmsnorm_from_splitk)
@@ -71,6 +72,7 @@ class LlamaTransformerLayer:
         self.layer_id = layer_id
         self.skinny = bool(getattr(engine_config, "use_skinny_gemm", False))
         self._qkv_splits = None     # k-splits the skinny GEMM picks for the fused qkv projection (cached)
+        self._qkv_even = None       # ... and whether they are even splits of whole 128-column tiles (the exact norm on the fly)
         self._tiny_ok = None        # can this layer run the tiny-batch (<= TINY_POLICY_M sequences) path (cached)
 
     def _split_qkv(self, qkv: torch.Tensor):
@@ -97,7 +99,7 @@ class LlamaTransformerLayer:
         # residual_buf <- input_embds + residual_buf ; input_embds <- rmsnorm(residual_buf)
         row_scale = None
         if isinstance(input_embds, RawResidual):        # the previous layer's down projection is already in residual_buf
-            return self._forward_from_raw_residual(residual_buf, k_cache, v_cache, block_table, st)
+            return self._forward_from_raw_residual(residual_buf, k_cache, v_cache, block_table, st, input_embds.ssq)
         if isinstance(input_embds, SplitKPartials):     # the previous layer's down projection, unreduced
             if self._tiny_decode_applies(st, input_embds, residual_buf):
                 return self._forward_decode_tiny(input_embds, residual_buf, k_cache, v_cache, block_table, st)
@@ -140,16 +142,39 @@ class LlamaTransformerLayer:
         return (getattr(ecfg, "rows_decode", False) and st.num_decoding_seqs <= max_m and self._deferred_attn_norm_ok(st)
                 and rows_add_ok(x, w_proj, residual_buf))
 
-    def _forward_from_raw_residual(self, residual_buf, k_cache, v_cache, block_table, st):
+    def _forward_from_raw_residual(self, residual_buf, k_cache, v_cache, block_table, st, ssq=None):
         """residual_buf holds the layer input r (the previous down projection added itself): qkv slabs of
-        round(r * attn_norm) with the 1/rms pending -> slab-fed attention -> the rest of the layer."""
+        round(r * attn_norm) with the 1/rms pending -> slab-fed attention -> the rest of the layer. With `ssq` (the rows'
+        per-tile sums of squares: the exact path) the slabs are those of the exactly normalised rows, nothing pending."""
         cfg, ecfg, w = self.model_config, self.engine_config, self.weight
-        qkv, pend = linear_splitk_nf(residual_buf, w.attn_norm, w.qkv_proj, cfg.rms_norm_eps)
+        if ssq is not None:
+            qkv, pend = linear_splitk_nx(residual_buf, w.attn_norm, w.qkv_proj, cfg.rms_norm_eps, ssq), None
+        else:
+            qkv, pend = linear_splitk_nf(residual_buf, w.attn_norm, w.qkv_proj, cfg.rms_norm_eps)
         # (the attention output is [tokens, heads * head_dim], which need not be the residual's width)
         o = residual_buf.new_empty((residual_buf.shape[0], cfg.num_q_heads * cfg.head_dim))
         paged_attention_from_qkv_splitk(qkv, k_cache, v_cache, block_table, cfg, ecfg, st, self.layer_id, o,
                                         row_scale=pend)
         return self._forward_after_attention(o, residual_buf, True, st)
+
+    def _rows_exact_applies(self, st, residual_buf, w_proj, x, max_m: int) -> bool:
+        """Row-owned projection + EXACT norm on the fly (r06c): where the deferred norm's policy says no — float16, the
+        reference's own precision — the same launches keep the reference's rounding points (csrc/gemm_rows.hip leaves the
+        rows' per-tile sums of squares, the consuming projection finishes the 1/rms before its first tile)."""
+        ecfg = self.engine_config
+        return (getattr(ecfg, "rows_decode", False) and getattr(ecfg, "fuse_splitk_consumers", True)
+                and st.num_decoding_seqs <= max_m and self._slab_fed_attention_applies(st)
+                and not self._deferred_attn_norm_ok(st) and residual_buf.shape[1] % 1024 == 0
+                and rows_add_ok(x, w_proj, residual_buf))
+
+    def _qkv_even_split_exists(self) -> bool:
+        """linear_splitk_nx takes even K splits of whole 128-column tiles only."""
+        if self._qkv_even is None:
+            from swiftllm_amd import _hip
+            w = self.weight.qkv_proj
+            ks = int(_hip.load().swl_gemm_skinny_packed_choose_splits(w.shape[0], w.shape[1]))
+            self._qkv_even = ks >= 1 and w.shape[1] % (128 * ks) == 0
+        return self._qkv_even
 
     def _qkv_splits_even(self) -> bool:
         """linear_splitk_nf takes even K splits only (set by _deferred_attn_norm_ok, which every caller checked first)."""
@@ -278,6 +303,16 @@ class LlamaTransformerLayer:
                     and nf_ok(residual_buf, w.qkv_proj, w.attn_norm) and self._qkv_splits_even()):
                 linear_rows_add(act, w.down_proj, residual_buf)
                 return RawResidual(residual_buf)
+            return linear_splitk(act, w.down_proj)
+        if (fast and st is not None and self._rows_exact_applies(st, residual_buf, w.o_proj, input_embds, self.ROWS_O_MAX_M)
+                and nx_ok(residual_buf, w.up_gate_proj, w.ffn_norm) and w.up_gate_proj.shape[0] % 64 == 0):
+            # the same two launches with the reference's rounding points: o_proj adds itself into the residual and leaves the
+            # rows' sums of squares, the SiLU-gate GEMM stages round(r * rstd * w)
+            ssq = linear_rows_add(input_embds, w.o_proj, residual_buf, with_ssq=True)
+            act = linear_silu_gate_nx(residual_buf, w.ffn_norm, cfg.rms_norm_eps, w.up_gate_proj, ssq)
+            if (st.num_decoding_seqs <= self.ROWS_DOWN_MAX_M and rows_add_ok(act, w.down_proj, residual_buf)
+                    and nx_ok(residual_buf, w.qkv_proj, w.attn_norm) and self._qkv_even_split_exists()):
+                return RawResidual(residual_buf, linear_rows_add(act, w.down_proj, residual_buf, with_ssq=True))
             return linear_splitk(act, w.down_proj)
         if fast:
             attn_out = linear_splitk(input_embds, w.o_proj)

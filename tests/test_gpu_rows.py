@@ -111,6 +111,60 @@ def test_norm_on_the_fly_projections(M):
     assert (a_old != a_new).float().mean().item() <= 1e-2
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M", [1, 8, 9, 32])
+def test_exact_norm_on_the_fly_is_rmsnorm_then_projection(dtype, M):
+    """r06c, the reference's rounding points on the row-owned path (float16 included): swl_gemm_rows_add_ssq leaves the bits of
+    swl_gemm_rows_add plus per-tile sums of squares of the updated rows (vs fp64: fp32 summation order); the consuming
+    projections (_nx) finish the 1/rms and stage round(r * rstd * w) themselves — against the product's own rmsnorm kernel
+    followed by the same GEMMs: identical up to the summation order of the sums of squares (a last-bit difference of rstd can
+    move an activation by one ulp: a small fraction of the elements, never more than an ulp of the row's scale)."""
+    from swiftllm_amd.worker.kernels.linear import (pack_weight, linear_rows_add, linear_silu_gate, linear_splitk,
+                                                    linear_silu_gate_nx, linear_splitk_nx, nx_ok)
+    from swiftllm_amd.worker.kernels.rmsnorm import rmsnorm_inplace
+    H, I, NQKV = 4096, 14336, 6144
+    g = gen(40 + M)
+    mk = lambda n, k: pack_weight_ret((torch.randn(n, k, generator=g) * 0.02).to(dtype).cuda())
+    wo, wug, wqkv = mk(H, H), mk(2 * I, H), mk(NQKV, H)
+    nw = (1.0 + 0.1 * torch.randn(H, generator=g)).to(dtype).cuda()
+    attn = torch.randn(M, H, generator=g).to(dtype).cuda()
+    r0 = torch.randn(M, H, generator=g).to(dtype).cuda()
+    eps = 1e-5
+    ra, rb = r0.clone(), r0.clone()
+    linear_rows_add(attn, wo, ra)
+    ssq = linear_rows_add(attn, wo, rb, with_ssq=True)
+    torch.cuda.synchronize()
+    assert torch.equal(ra, rb)
+    want_ssq = (rb.double() ** 2).view(M, H // 16, 16).sum(-1)
+    assert ((ssq.double() - want_ssq).abs() <= 1e-5 * want_ssq.abs() + 1e-12).all()
+    assert nx_ok(rb, wug, nw) and nx_ok(rb, wqkv, nw)
+    xn = rb.clone()
+    rmsnorm_inplace(xn, nw, eps)
+    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    # SiLU-gate
+    want = linear_silu_gate(xn, wug)
+    got = linear_silu_gate_nx(rb, nw, eps, wug, ssq)
+    torch.cuda.synchronize()
+    scale = want.float().abs().amax(dim=1, keepdim=True).clamp(min=1e-3)
+    assert ((got.float() - want.float()).abs() <= 2 * ulp * scale).all()
+    assert (got != want).float().mean().item() <= 2e-2
+    # fused qkv slabs
+    sk = linear_splitk(xn, wqkv, always=True)
+    want_q = sk.slabs[: sk.k_splits * M * NQKV].clone().view(sk.k_splits, M, NQKV).sum(0)
+    nx = linear_splitk_nx(rb, nw, wqkv, eps, ssq)
+    assert nx is not None and nx.k_splits == sk.k_splits
+    got_q = nx.slabs[: nx.k_splits * M * NQKV].view(nx.k_splits, M, NQKV).sum(0)
+    torch.cuda.synchronize()
+    qs = want_q.abs().amax(dim=1, keepdim=True).clamp(min=1e-3)
+    assert ((got_q - want_q).abs() <= 2 * ulp * qs).all()
+
+
+def pack_weight_ret(w):
+    from swiftllm_amd.worker.kernels.linear import pack_weight
+    pack_weight(w)
+    return w
+
+
 def _engine_config(path, **kw):
     from swiftllm_amd import EngineConfig
     base = dict(model_path=path, use_dummy=False, block_size=16, gpu_mem_utilization=0.9, num_cpu_blocks=8,
@@ -119,8 +173,9 @@ def _engine_config(path, **kw):
     return EngineConfig(**base)
 
 
-@pytest.mark.parametrize("batch", [1, 2, 8, 9, 16, 17, 32])
-def test_rows_decode_path_equals_the_consumer_path(tmp_path, batch):
+@pytest.mark.parametrize("batch,dtype", [(b, "bfloat16") for b in (1, 2, 8, 9, 16, 17, 32)] +
+                         [(b, "float16") for b in (1, 9, 17, 32)])
+def test_rows_decode_path_equals_the_consumer_path(tmp_path, batch, dtype, monkeypatch):
     """The rows_decode switch at Llama-3-8B layer geometry (3 layers): the engine with row-owned o_proj / down_proj + norm on
     the fly against the same engine with the split-K + consumer launches (and the <= 2-sequence tiny path), teacher-forced over
     6 decode steps, with hipGraph replay and with eager launches: logits within the storage dtype's rounding (the arithmetic
@@ -129,8 +184,7 @@ def test_rows_decode_path_equals_the_consumer_path(tmp_path, batch):
     ROWS_DOWN_MAX_M (16 | 17) and at ROWS_O_MAX_M (32)."""
     cfg = synth.make_config(num_hidden_layers=3, hidden_size=4096, num_attention_heads=32, num_key_value_heads=8,
                             intermediate_size=14336, vocab_size=4096, max_position_embeddings=2048, rope_theta=500000.0)
-    dtype = "bfloat16"
-    sd = synth.make_state_dict(cfg, seed=19, dtype=torch.bfloat16)
+    sd = synth.make_state_dict(cfg, seed=19, dtype=getattr(torch, dtype))
     g = torch.Generator().manual_seed(5)
     lens = ([300, 17, 1, 64, 129, 40, 33, 250] * 4)[:batch]
     prompts = [torch.randint(0, cfg["vocab_size"], (n,), generator=g).tolist() for n in lens]
@@ -156,10 +210,23 @@ def test_rows_decode_path_equals_the_consumer_path(tmp_path, batch):
         torch.cuda.empty_cache()
         return toks, logits
 
+    from swiftllm_amd import _hip
+    calls, real_call = [], _hip.call
+
+    def spy(name, *args):
+        calls.append(name)
+        return real_call(name, *args)
+    monkeypatch.setattr(_hip, "call", spy)
     ref_toks, ref_logits = run(dict(tuning=dict(rows_decode=False)))
-    eps = 2.0 ** -7
+    assert not any(c.startswith("swl_gemm_rows_add") for c in calls)
+    calls.clear()
+    eps = 2.0 ** -7 if dtype == "bfloat16" else 2.0 ** -10     # (float16: the exact norm on the fly, r06c)
     for opts in (dict(), dict(use_hip_graph=False)):
         toks, logits = run(opts, forced=ref_toks)
+        # the path under test really ran: bfloat16 the deferred norm on the fly, float16 the exact one
+        assert ("swl_gemm_rows_add_ssq" if dtype == "float16" else "swl_gemm_rows_add") in calls, sorted(set(calls))
+        assert ("swl_gemm_skinny_packed_silu_gate_nx" if dtype == "float16" else "swl_gemm_skinny_packed_silu_gate_nf") in calls
+        assert ("swl_gemm_skinny_packed_partial_nx" in calls) == (dtype == "float16" and batch <= 16), sorted(set(calls))
         for step, (a, b) in enumerate(zip(logits, ref_logits)):
             scale = b.abs().amax(dim=1, keepdim=True).clamp(min=1.0)
             assert ((a - b).abs() <= 4 * eps * scale).all(), (opts, step, ((a - b).abs() / scale).max().item())

@@ -325,13 +325,28 @@ __global__ __launch_bounds__(NWV * 64, NWV == 2 ? 1 : 2) void gemm_skinny_ring_k
 #pragma unroll
             for (int e = 0; e < 8; ++e) nx_part[it][e] = 0.f;
             if (item < 256) {
-                for (int c = 0; c < per; c += 8) {          // (per % 8 == 0 is checked by the host: 32-byte runs)
-                    const float4_t u0 = *reinterpret_cast<const float4_t *>(src + c);
-                    const float4_t u1 = *reinterpret_cast<const float4_t *>(src + c + 4);
+                if (per == 32) {
+                    // hidden = 4096: the piece is 128 bytes — all eight requests before the first add (a load inside the
+                    // accumulation loop below is waited for on the spot: four round trips in a row instead of one)
+                    float4_t u[8];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        nx_part[it][e] += u0[e];
-                        nx_part[it][4 + e] += u1[e];
+                    for (int j = 0; j < 8; ++j) u[j] = *reinterpret_cast<const float4_t *>(src + 4 * j);
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            nx_part[it][e] += u[j][e];
+                            nx_part[it][4 + e] += u[j + 1][e];
+                        }
+                } else {
+                    for (int c = 0; c < per; c += 8) {      // (per % 8 == 0 is checked by the host: 32-byte runs)
+                        const float4_t u0 = *reinterpret_cast<const float4_t *>(src + c);
+                        const float4_t u1 = *reinterpret_cast<const float4_t *>(src + c + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            nx_part[it][e] += u0[e];
+                            nx_part[it][4 + e] += u1[e];
+                        }
                     }
                 }
             }

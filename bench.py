@@ -222,9 +222,17 @@ def step_roofline(cfg, e, batch, mean_ctx, ms_per_step):
     kvt = kv_token_bytes(cfg, e)
     step_bytes = W + batch * mean_ctx * kvt + batch * kvt
     gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
+    # the other roof (at 128 / 256 tokens the projections approach the ridge): 2 flops per weight per
+    # token + QK^T and PV over the context; time at the dense MFMA peak next to time at the HBM peak
+    h, L = cfg["hidden_size"], cfg["num_hidden_layers"]
+    flops = 2.0 * batch * (W / e) + 4.0 * batch * mean_ctx * h * L
+    t_hbm_ms, t_mfma_ms = step_bytes / (HBM_PEAK_GBS * 1e9) * 1e3, flops / (MFMA_PEAK_TFLOPS * 1e12) * 1e3
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy": round(gbs / HBM_COPY_GBS, 4),
-            "bytes_per_step": int(step_bytes), "weights_bytes": int(W), "kv_bytes": int(step_bytes - W)}
+            "bytes_per_step": int(step_bytes), "weights_bytes": int(W), "kv_bytes": int(step_bytes - W),
+            "mfma_roof": {"flops_per_step": int(flops), "achieved_tflops": round(flops / (ms_per_step * 1e-3) / 1e12, 1),
+                          "peak_tflops": MFMA_PEAK_TFLOPS, "frac": round(t_mfma_ms / ms_per_step, 4),
+                          "ms_at_mfma_peak": round(t_mfma_ms, 3), "ms_at_hbm_peak": round(t_hbm_ms, 3)}}
 
 
 class DecodeRun:

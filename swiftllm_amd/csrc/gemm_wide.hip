@@ -48,19 +48,30 @@ enum WideMode { kWideDirect = 0, kWidePartial = 1, kWideSiluGate = 2 };
 
 // 4-wave workgroups with more than 4 token blocks run ONE wave per SIMD (launch bound 1: the whole 512-register file per
 // wave — 96-128 accumulator registers, two x register sets and a 6-deep weight ring, 20 KiB per wave in flight).
-template <typename T, int MT, int NWV, int MODE>
-__global__ __launch_bounds__(NWV * 64, (NWV == 4 && MT > 4) ? 1 : 2) void gemm_packed_wide_kernel(
+//
+// TS (token split, r06d): with TS = 1 every MFMA reads its own B fragment from LDS — 1 KiB per MFMA, and four waves doing
+// that ask the CU's 128 B/clk LDS port for exactly as many cycles as the matrix cores are busy. TS = 2 tiles the wave's
+// registers in BOTH directions: a wave owns TWO 32-row blocks of W (64 rows) and HALF of the token blocks, so each B
+// fragment feeds two MFMAs (LDS reads halve) while the accumulator count stays MT; its sibling wave takes the other token
+// half of the same rows (W is requested by both: the second request is an L1 / L2 hit). Same workgroup footprint (NWV * 32
+// rows of W x all tokens), same K order per output: the bits do not change.
+template <typename T, int MT, int NWV, int MODE, int TS>
+__global__ __launch_bounds__(NWV * 64, (NWV == 4 && (MT > 4 || TS == 2 || MODE == kWideSiluGate)) ? 1 : 2) void gemm_packed_wide_kernel(
     void *__restrict__ out_, const T *__restrict__ x, const T *__restrict__ wpk, int M, int N, int K, int kc,
     int64_t x_stride, int64_t out_stride) {
     constexpr int NT = NWV * 64;
+    constexpr int RB = TS;                       // 32-row blocks of W per wave
+    constexpr int MTW = MT / TS;                 // token blocks per wave
+    static_assert(MT % TS == 0 && (NWV / 2) % TS == 0, "token split must divide the token blocks and the wave halves");
     constexpr int XL = MT * 256 / NT;            // 16-byte chunks of the x tile each thread stages
     constexpr int RPP = NT / 8;                  // rows per staging pass (8 chunks per row)
     constexpr int kXTile = MT * 32 * kWT;
     constexpr int HW = NWV / 2;
     // x prefetch distance in steps: 2 where two register sets fit beside the accumulators, else 1; W ring depth in tiles
-    constexpr bool kBig = NWV == 4 && MT > 4;    // one wave per SIMD
+    constexpr bool kBig = NWV == 4 && (MT > 4 || TS == 2 || MODE == kWideSiluGate);   // one wave per SIMD
+    constexpr int BQ = (NWV == 4 && MODE == kWideSiluGate && MT <= 6) ? 2 : 1;   // B-fragment register sets (SWL_W_PROCESS)
     constexpr int XD = (MT >= 8 && !kBig) ? 1 : 2;
-    constexpr int kWD = kBig ? 6 : 4;
+    constexpr int kWD = TS == 2 ? (MT >= 8 ? 3 : 4) : (kBig ? 6 : 4);   // a TS = 2 slot is two fragments: 8 KiB per wave
     static_assert(MT * 256 % NT == 0, "x tile must split evenly over the workgroup");
     __shared__ __attribute__((aligned(16))) T xs[2 * kXTile];
 
@@ -68,7 +79,10 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 4 && MT > 4) ? 1 : 2) void gemm_p
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool is_gate = MODE == kWideSiluGate && wave >= HW;
-    const int col0 = MODE == kWideSiluGate ? (blockIdx.x * HW + (wave % HW)) * 32 : (blockIdx.x * NWV + wave) * 32;
+    // wave -> (row group, token part): TS consecutive waves share a row group; SiLU-gate mode numbers them inside each half
+    const int wslot = MODE == kWideSiluGate ? wave % HW : wave;
+    const int tp = wslot % TS;
+    const int col0 = ((MODE == kWideSiluGate ? blockIdx.x * (HW / TS) : blockIdx.x * (NWV / TS)) + wslot / TS) * (32 * RB);
     const bool tile_ok = col0 < N;
     const int nt = tile_ok ? (col0 + (is_gate ? N : 0)) / 32 : 0;
     const int ksplit = blockIdx.y;
@@ -86,15 +100,19 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 4 && MT > 4) ? 1 : 2) void gemm_p
     const int l32 = lane & 31, hf = lane >> 5;
     const int swz = (l32 >> 1) & 7;
 
-    vec8_t<T> wr[kWD][4], xr[XD][XL];
-    float16_t acc[MT];
+    const int64_t wrb = static_cast<int64_t>(K / 16) * 512;   // the next 32-row block of W
+    // W is streamed once: non-temporal — except with TS = 2, where the sibling wave asks for the same lines a moment later
+    auto load_w = [](const T *p) { return TS == 2 ? load8(p) : load8_nt(p); };
+    vec8_t<T> wr[kWD][RB * 4], xr[XD][XL];
+    float16_t acc[MT];                                         // [row block][token block of this wave]
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = float16_t{};
 
 #define SWL_W_ISSUE_W(slot, tile)                                                                     \
     {                                                                                                \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                             \
-            wr[slot][i_] = load8_nt(wsrc + (static_cast<int64_t>(tile) * 4 + i_) * 512);              \
+        _Pragma("unroll") for (int rb_ = 0; rb_ < RB; ++rb_)                                         \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                         \
+                wr[slot][rb_ * 4 + i_] = load_w(wsrc + rb_ * wrb + (static_cast<int64_t>(tile) * 4 + i_) * 512); \
     }
 #define SWL_W_ISSUE_X(set, tile)                                                                      \
     {                                                                                                \
@@ -105,15 +123,31 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 4 && MT > 4) ? 1 : 2) void gemm_p
         _Pragma("unroll") for (int q_ = 0; q_ < XL; ++q_)                                            \
             *reinterpret_cast<vec8_t<T> *>(xs + (buf) * kXTile + xs_wr0 + q_ * RPP * kWT) = xr[set][q_]; \
     }
+// SiLU-gate form up to 192 tokens (BQ = 2): the B fragments of k-step kk+1 are requested BEFORE the MFMAs of k-step kk (two
+// register sets, pinned by scheduling barriers). Left to itself the compiler issues each pair of ds_reads right in front of
+// the two MFMAs that consume them (`dd w M w M` in tools/isa_mix.py --seq). Measured (profiles/r06d_gemm_wide_pipe_ab.jsonl):
+// up/gate + SiLU 51.5 vs 55.2 us at 96 tokens, 54.1 vs 55.9 at 128, 71.0 vs 76.5 at 192; the partial-slab kernels (qkv, o,
+// down) are 1-4 us SLOWER with it at 256 tokens and level below, and keep one set.
 #define SWL_W_PROCESS(slot, buf)                                                                      \
     {                                                                                                \
-        const T *xl_ = xs + (buf) * kXTile + l32 * kWT;                                              \
+        const T *xl_ = xs + (buf) * kXTile + (tp * MTW * 32 + l32) * kWT;                            \
+        vec8_t<T> bq_[BQ][MTW];                                                                      \
+        if constexpr (BQ == 2) {                                                                     \
+            _Pragma("unroll") for (int mt_ = 0; mt_ < MTW; ++mt_)                                    \
+                bq_[0][mt_] = *reinterpret_cast<const vec8_t<T> *>(xl_ + mt_ * 32 * kWT + ((hf ^ swz) << 3)); \
+        }                                                                                            \
         _Pragma("unroll") for (int kk_ = 0; kk_ < kWT / 16; ++kk_) {                                 \
-            const int off_ = ((2 * kk_ + hf) ^ swz) << 3;                                            \
-            _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) {                                   \
-                const vec8_t<T> b_ = *reinterpret_cast<const vec8_t<T> *>(xl_ + mt_ * 32 * kWT + off_); \
-                acc[mt_] = mfma_w(wr[slot][kk_], b_, acc[mt_]);                                      \
+            const int nk_ = BQ == 2 ? kk_ + 1 : kk_;                                                 \
+            if (nk_ < kWT / 16) {                                                                    \
+                const int off_ = ((2 * nk_ + hf) ^ swz) << 3;                                        \
+                _Pragma("unroll") for (int mt_ = 0; mt_ < MTW; ++mt_)                                \
+                    bq_[nk_ % BQ][mt_] = *reinterpret_cast<const vec8_t<T> *>(xl_ + mt_ * 32 * kWT + off_); \
             }                                                                                        \
+            if constexpr (BQ == 2) __builtin_amdgcn_sched_barrier(0);                                \
+            _Pragma("unroll") for (int mt_ = 0; mt_ < MTW; ++mt_)                                    \
+                _Pragma("unroll") for (int rb_ = 0; rb_ < RB; ++rb_)                                 \
+                    acc[rb_ * MTW + mt_] = mfma_w(wr[slot][rb_ * 4 + kk_], bq_[kk_ % BQ][mt_], acc[rb_ * MTW + mt_]); \
+            if constexpr (BQ == 2) __builtin_amdgcn_sched_barrier(0);                                \
         }                                                                                            \
     }
     // Tile t is multiplied in step t. Its x tile was requested in step t-2 (an L2 round trip under load is longer than
@@ -161,7 +195,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 4 && MT > 4) ? 1 : 2) void gemm_p
     for (int mt = 0; mt < MT; ++mt) mfma_results_tie(acc[mt]);
     mfma_results_ready<8>(acc[MT - 1]); // acc comes straight out of the K loop (swl_common.h)
 
-    // acc[mt][r] = out^T[n = col0 + (r&3) + 8*(r>>2) + 4*hf][m = 32*mt + l32]
+    // acc[a][r], a = rb * MTW + mt: out^T[n = col0 + 32*rb + (r&3) + 8*(r>>2) + 4*hf][m = 32*(tp*MTW + mt) + l32]
     if constexpr (MODE == kWideSiluGate) {
         constexpr int MTR = MT / 2;     // token blocks per exchange round: HW * MTR tiles of 32 x 40 elements fit the x buffers
         static_assert(HW * MTR * 1280 <= 2 * kXTile, "exchange tiles must fit the x buffers");
@@ -184,9 +218,9 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 4 && MT > 4) ? 1 : 2) void gemm_p
 #pragma unroll
                 for (int j = 0; j < MTR; ++j) {
                     const int mt = round * MTR + j;
-                    const int m = 32 * mt + l32;
+                    const int m = 32 * (tp * MTW + mt % MTW) + l32;
                     if (m >= M) continue;
-                    T *o = static_cast<T *>(out_) + static_cast<int64_t>(m) * out_stride + col0 + 4 * hf;
+                    T *o = static_cast<T *>(out_) + static_cast<int64_t>(m) * out_stride + col0 + 32 * (mt / MTW) + 4 * hf;
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
                         const vec4 a = *reinterpret_cast<const vec4 *>(xch + j * 1280 + l32 * 40 + 8 * r4 + 4 * hf);
@@ -203,9 +237,9 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 4 && MT > 4) ? 1 : 2) void gemm_p
     if (!tile_ok) return;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int m = 32 * mt + l32;
+        const int m = 32 * (tp * MTW + mt % MTW) + l32;
         if (m >= M) continue;
-        const int n = col0 + 4 * hf;
+        const int n = col0 + 32 * (mt / MTW) + 4 * hf;
         if constexpr (MODE == kWidePartial) {
             float *slab = static_cast<float *>(out_) + (static_cast<int64_t>(ksplit) * M + m) * N + n;
 #pragma unroll
@@ -230,7 +264,27 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 4 && MT > 4) ? 1 : 2) void gemm_p
 struct WidePlan {
     int nwv;    // waves per workgroup: 8 (256 rows of W) or 4 (128 rows)
     int ks;     // K splits (fp32 slabs when > 1)
+    int ts;     // token split inside a row group: 1, or 2 (4-wave groups, N % 64 == 0; see the kernel's TS note)
 };
+
+// SWL_WIDE_TS=1|2 forces one register tiling of the plain / partial kernels (A/B runs); unset: the measured choice below.
+static int wide_ts_forced() {
+    static const int v = [] {
+        const char *e = getenv("SWL_WIDE_TS");
+        return e && (e[0] == '1' || e[0] == '2') ? e[0] - '0' : 0;
+    }();
+    return v;
+}
+// Measured (profiles/r06d_gemm_wide_token_split_ab.jsonl, weights cycled through 1.2 GB): with K-chunks of <= 16 K-tiles
+// — the qkv and o projections — TS = 2 is 5-9 % faster up to 192 tokens (qkv 23.6 vs 25.4 us at 128, 29.6 vs 32.4 at
+// 192; o 23.7 vs 26.1 at 192) and level at 256; the long chunks of down_proj (28 tiles) and the SiLU-gate form are 3-15 %
+// SLOWER with it and keep TS = 1.
+static int wide_ts(int M, int N, int kc, int nwv, bool silu) {
+    if (nwv != 4 || (N & 63) || silu) return 1;
+    const int f = wide_ts_forced();
+    if (f) return f;
+    return (kc <= 16 * kWT && M <= 192) ? 2 : 1;
+}
 
 // Workgroup width and K-split for (M, N, K), from the sweeps on MI355X (profiles/r04c_/r04d_gemm_wide_micro.jsonl,
 // Llama-3-8B widths, bf16, M = 96..256): 4-wave workgroups everywhere (two per CU up to 128 tokens, one wave per SIMD
@@ -246,23 +300,30 @@ static WidePlan gemm_wide_plan(int M, int N, int K, int forced_nwv, int forced_k
     int ks = 1;
     while (ks < 16 && wgs * ks * 2 <= 256 && K % (kWT * ks * 2) == 0 && K / (ks * 2) >= min_chunk) ks *= 2;
     p.ks = forced_ks ? forced_ks : ks;
+    p.ts = wide_ts(M, N, K / p.ks, p.nwv, false);
     return p;
 }
 
 template <typename T, int MODE>
-static void launch_wide(int mt, int nwv, dim3 grid, hipStream_t s, void *out, const T *x, const T *wp, int M, int N, int K,
-                        int kc, int64_t xs, int64_t os) {
-#define SWL_W_LAUNCH(MT_, NWV_)                                                                                     \
-    hipLaunchKernelGGL((gemm_packed_wide_kernel<T, MT_, NWV_, MODE>), grid, dim3(NWV_ * 64), 0, s, out, x, wp, M, N, K, \
-                       kc, xs, os)
+static void launch_wide(int mt, int nwv, int ts, dim3 grid, hipStream_t s, void *out, const T *x, const T *wp, int M, int N,
+                        int K, int kc, int64_t xs, int64_t os) {
+#define SWL_W_LAUNCH(MT_, NWV_, TS_)                                                                                \
+    hipLaunchKernelGGL((gemm_packed_wide_kernel<T, MT_, NWV_, MODE, TS_>), grid, dim3(NWV_ * 64), 0, s, out, x, wp, M, N, \
+                       K, kc, xs, os)
     if (nwv == 8) {
-        if (mt <= 4) SWL_W_LAUNCH(4, 8);
-        else if (mt <= 6) SWL_W_LAUNCH(6, 8);
-        else SWL_W_LAUNCH(8, 8);
+        if (mt <= 4) SWL_W_LAUNCH(4, 8, 1);
+        else if (mt <= 6) SWL_W_LAUNCH(6, 8, 1);
+        else SWL_W_LAUNCH(8, 8, 1);
+    } else if (ts == 2 && MODE != kWideSiluGate) {
+        if constexpr (MODE != kWideSiluGate) {
+            if (mt <= 4) SWL_W_LAUNCH(4, 4, 2);
+            else if (mt <= 6) SWL_W_LAUNCH(6, 4, 2);
+            else SWL_W_LAUNCH(8, 4, 2);
+        }
     } else {
-        if (mt <= 4) SWL_W_LAUNCH(4, 4);
-        else if (mt <= 6) SWL_W_LAUNCH(6, 4);
-        else SWL_W_LAUNCH(8, 4);
+        if (mt <= 4) SWL_W_LAUNCH(4, 4, 1);
+        else if (mt <= 6) SWL_W_LAUNCH(6, 4, 1);
+        else SWL_W_LAUNCH(8, 4, 1);
     }
 #undef SWL_W_LAUNCH
 }
@@ -303,7 +364,7 @@ extern "C" int swl_gemm_packed_wide(void *out, const void *x, const void *w_pack
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (p.ks == 1) {
         SWL_DISPATCH_DTYPE(dtype, T, {
-            swl::launch_wide<T, swl::kWideDirect>(mt, p.nwv, grid, s, out, static_cast<const T *>(x),
+            swl::launch_wide<T, swl::kWideDirect>(mt, p.nwv, p.ts, grid, s, out, static_cast<const T *>(x),
                                                   static_cast<const T *>(w_packed), M, N, K, kc, x_row_stride,
                                                   out_row_stride);
         });
@@ -311,7 +372,7 @@ extern "C" int swl_gemm_packed_wide(void *out, const void *x, const void *w_pack
     }
     if (!workspace || workspace_bytes < static_cast<size_t>(p.ks) * M * N * sizeof(float)) return SWL_ERR_BAD_ARG;
     SWL_DISPATCH_DTYPE(dtype, T, {
-        swl::launch_wide<T, swl::kWidePartial>(mt, p.nwv, grid, s, workspace, static_cast<const T *>(x),
+        swl::launch_wide<T, swl::kWidePartial>(mt, p.nwv, p.ts, grid, s, workspace, static_cast<const T *>(x),
                                                static_cast<const T *>(w_packed), M, N, K, kc, x_row_stride, N);
     });
     if (swl::check_launch() != SWL_OK) return SWL_ERR_LAUNCH;
@@ -343,7 +404,7 @@ extern "C" int swl_gemm_packed_wide_partial(float *slabs, size_t slabs_bytes, co
     const swl::WidePlan p = swl::gemm_wide_plan(M, N, K, waves_per_group, k_splits);
     const dim3 grid((N / 32 + p.nwv - 1) / p.nwv, p.ks);
     SWL_DISPATCH_DTYPE(dtype, T, {
-        swl::launch_wide<T, swl::kWidePartial>((M + 31) / 32, p.nwv, grid, static_cast<hipStream_t>(stream), slabs,
+        swl::launch_wide<T, swl::kWidePartial>((M + 31) / 32, p.nwv, p.ts, grid, static_cast<hipStream_t>(stream), slabs,
                                                static_cast<const T *>(x), static_cast<const T *>(w_packed), M, N, K,
                                                K / p.ks, x_row_stride, N);
     });
@@ -371,7 +432,7 @@ extern "C" int swl_gemm_packed_wide_silu_gate(void *out, const void *x, const vo
     const dim3 grid((I / 32 + hw - 1) / hw, 1);
     hipStream_t s = static_cast<hipStream_t>(stream);
     SWL_DISPATCH_DTYPE(dtype, T, {
-        swl::launch_wide<T, swl::kWideSiluGate>(mt, nwv, grid, s, out, static_cast<const T *>(x),
+        swl::launch_wide<T, swl::kWideSiluGate>(mt, nwv, 1, grid, s, out, static_cast<const T *>(x),
                                                 static_cast<const T *>(w_up_gate_packed), M, I, K, K, x_row_stride,
                                                 out_row_stride);
     });

@@ -3,7 +3,7 @@
 shapes of a Llama-3-8B decode layer, for decode batches of 65..256 tokens (GPU). Checks every variant against an fp32
 reference first, then times it with HIP events over launches that cycle through 8 distinct weight copies (far past the
 256 MiB Infinity Cache for the big shapes). One JSON line per (shape, M)."""
-import argparse, json, os, sys
+import argparse, hashlib, json, os, sys
 import torch
 import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,6 +26,11 @@ def time_us(fn, iters, warm=3):
     return s.elapsed_time(e) * 1e3 / iters
 
 
+def sha(t):
+    """Digest of a result tensor's bits (runs with different SWL_WIDE_TS / variant libraries must agree on it)."""
+    return hashlib.sha1(t.contiguous().view(torch.uint8).cpu().numpy().tobytes()).hexdigest()[:12]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--m", default="96,128,192,256")
@@ -33,20 +38,24 @@ def main():
     ap.add_argument("--dtype", default="bfloat16")
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--copies", type=int, default=6)
+    ap.add_argument("--cycle-mb", type=float, default=1200.0, help="minimum total size of the weight copies cycled through")
     ap.add_argument("--auto-only", action="store_true", help="the library's own plan only, no hipBLASLt timing (for PMC passes)")
     a = ap.parse_args()
     dtype = getattr(torch, a.dtype)
     code = _hip.dtype_code(dtype)
     g = torch.Generator(device="cuda").manual_seed(0)
+    tag = dict(ts=os.environ.get("SWL_WIDE_TS", "auto"), lib=os.path.basename(os.environ.get("SWIFTLLM_HIP_LIB", "product")))
     for name in a.shapes.split(","):
         N, K = SHAPES[name]
-        copies = a.copies if N * K * 2 < (1 << 30) else 2
+        # cycle through enough copies that a re-read never finds its lines in the 256 MiB Infinity Cache (r06d: with 6 copies
+        # of the 34 MB o_proj weight, plain loads looked 10 % faster than non-temporal ones — an artefact of 204 MB of weights)
+        copies = max(a.copies, -(-int(a.cycle_mb * 1e6) // (N * K * 2))) if N * K * 2 < (1 << 30) else 2
         ws = [(torch.randn(N, K, device="cuda", generator=g) * 0.02).to(dtype) for _ in range(copies)]
         wps = [pack_weight(w) for w in ws]
         for M in [int(x) for x in a.m.split(",")]:
             x = torch.randn(M, K, device="cuda", generator=g).to(dtype)
             ref = x.float() @ ws[0].float().t()
-            row = dict(shape=name, M=M, N=N, K=K, MB=round(N * K * 2 / 1e6, 1))
+            row = dict(shape=name, M=M, N=N, K=K, MB=round(N * K * 2 / 1e6, 1), copies=copies, **tag)
             if not a.auto_only:
                 row["blas_us"] = round(time_us(lambda i: F.linear(x, ws[i % copies]), a.iters), 2)
             out = torch.empty(M, N, device="cuda", dtype=dtype)
@@ -64,6 +73,8 @@ def main():
                 key = f"w{nw}k{ks}" if nw else "auto"
                 row[key + "_us"] = round(time_us(run, a.iters), 2)
                 row[key + "_relerr"] = round(err, 5)
+                run(0)
+                row[key + "_sha"] = sha(out)
             if name == "up_gate":
                 I = N // 2
                 og = torch.empty(M, I, device="cuda", dtype=dtype)
@@ -83,6 +94,8 @@ def main():
                     run(0)
                     row[f"silu_w{nw}_relerr"] = round(float((og.float() - want.float()).abs().max() / want.float().abs().max()), 5)
                     row[f"silu_w{nw}_us"] = round(time_us(run, a.iters), 2)
+                    run(0)
+                    row[f"silu_w{nw}_sha"] = sha(og)
             print(json.dumps(row), flush=True)
         del ws, wps
         torch.cuda.empty_cache()

@@ -809,6 +809,7 @@ def test_gemm_packed_wide_vs_fp32_reference(dtype, M, N, K):
         mid = torch.empty(M, N, dtype=dtype, device="cuda")
         _hip.call("swl_gemm_packed_mid", mid.data_ptr(), x.data_ptr(), wp.data_ptr(), 0, 0, M, N, K, K, N, 1, code,
                   _hip.stream())
+    by_split = {}
     for nwv in (0, 4, 8):
         for ks in (0, 1, 2, 4, 8):
             if ks and K % (64 * ks):
@@ -819,6 +820,10 @@ def test_gemm_packed_wide_vs_fp32_reference(dtype, M, N, K):
             assert ((out.float() - ref).abs() <= eps * ref.abs() + 1e-3 * eps * (K ** 0.5)).all(), (nwv, ks)
             if ks == 1 and mid is not None:
                 assert torch.equal(out, mid), nwv
+            if ks:
+                # the register tiling is not allowed to show: 4-wave groups (token split where the plan picks it, r06d)
+                # and 8-wave groups (never split) sum every output in the same K order
+                assert torch.equal(by_split.setdefault(ks, out), out), (nwv, ks)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

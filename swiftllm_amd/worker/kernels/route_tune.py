@@ -36,25 +36,30 @@ _device_key_cache = {}
 
 
 def table_wide_wins(m: int, n: int, k: int) -> bool:
-    """profiles/r04c_ / r04d_gemm_wide_micro.jsonl, Llama-3-8B widths, bf16, MI355X, us ours / library at M = 96, 128, 160, 192,
-    224, 256:
+    """Llama-3-8B widths, bf16, MI355X, us ours / library. r04 sweep (profiles/r04c_ / r04d_gemm_wide_micro.jsonl; M = 96, 128,
+    160, 192, 224, 256):
         down (K >= 2N)   33/63  34/75  43/85  44/104  52/60  54/63      -> always
-        qkv  (N = 6144)  23/23  25/26  32/29  32/34   37/37  37/40      -> except (128, 160]
-        o    (N = 4096)  20/20  21/22  26/24  26/29   29/21  30/21      -> up to 128 and (160, 192]
-    (the library's 160-token kernels are good, its 192-token ones are not). The plain up/gate projection only ties (53 / 54 at
-    128) and loses beyond; its SiLU-gate form is `table_wide_silu_wins`."""
+    qkv and o re-measured in r06d (profiles/r06d_gemm_wide_routing_remeasure.jsonl) with the weights cycled through 1.2 GB —
+    the r04 sweep's six copies left 200-300 MB of them in the Infinity Cache, which flattered the library's 160-token
+    kernels (o: 24 us then, 31.5 cold) — and with the token-split tiling of csrc/gemm_wide.hip; M = 136, 144, 160, 176, 192,
+    208, 224, 256:
+        qkv  (N = 6144)  27/41  27/41  28/31  29/30  29/37  37/30  37/40  38/43   -> except (192, 208]
+        o    (N = 4096)  22/28  22/24  22/32  23/26  24/36  29/27  29/29  30/27   -> up to 192
+    (up to 128 tokens both were already ours.) The plain up/gate projection only ties (53 / 54 at 128) and loses beyond;
+    its SiLU-gate form is `table_wide_silu_wins`."""
     if k >= 2 * n:
         return True
     if n > 8192:
         return False
-    if m <= 128 or 160 < m <= 192:
+    if m <= 192:
         return True
-    return m > 192 and n > 4096
+    return n > 4096 and m > 208
 
 
 def table_wide_silu_wins(m: int) -> bool:
     """up/gate projection + SiLU-gate in one launch against the library GEMM + silu_and_mul: 53.5 / 63.3 us at 128 tokens,
-    60.0 / 62.5 at 96; 88 / 73 at 192 (six token blocks per fragment leave too few waves per CU): up to 128 tokens."""
+    60.0 / 62.5 at 96; r06d (pipelined B fragments, cold weights): 81 / 71 at 136, 77 / 71 at 160, 81 / 76 at 192, 108 / 87 at
+    256: up to 128 tokens."""
     return m <= 128
 
 

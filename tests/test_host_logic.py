@@ -421,7 +421,7 @@ def test_wide_kernel_routing_is_decided_once_per_deployment(tmp_path, monkeypatc
     monkeypatch.setattr(R, "_device_key_cache", {"cpu": "test-device|hip x|torch y"})
     bf16, f16 = torch.bfloat16, torch.float16
     assert R.decide(128, 4096, 14336, bf16, False) is True         # down: the table
-    assert R.decide(160, 4096, 4096, bf16, False) is False         # o_proj at 160: library
+    assert R.decide(224, 4096, 4096, bf16, False) is False         # o_proj at 224: library
     assert R.decide(192, 28672, 4096, bf16, True) is False         # SiLU-gate form > 128 tokens
     assert R.decide(100, 5120, 5120, bf16, False) is False         # nobody measured: the library, deterministically
     assert R.decide(100, 4096, 4096, f16, False) is False          # float16 at a measured (N, K) is not the measured class
@@ -716,14 +716,15 @@ def test_spawn_local_ranks_kills_a_rank_that_ignores_sigterm(monkeypatch):
 
 
 def test_wide_gemm_routing_is_the_measured_table():
-    """kernels/linear.py: _wide_wins / _wide_silu_wins encode profiles/r04c_/r04d_gemm_wide_micro.jsonl (Llama-3-8B widths)."""
+    """kernels/linear.py: _wide_wins / _wide_silu_wins encode profiles/r04c_/r04d_gemm_wide_micro.jsonl and, for qkv / o, the
+    r06d re-measurement profiles/r06d_gemm_wide_routing_remeasure.jsonl (Llama-3-8B widths)."""
     from swiftllm_amd.worker.kernels.linear import _wide_wins, _wide_silu_wins
     qkv, o, up_gate, down, lm_head = (6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336), (128256, 4096)
     for m in (65, 96, 128, 160, 192, 224, 256):
         assert _wide_wins(m, *down)
         assert not _wide_wins(m, *up_gate) and not _wide_wins(m, *lm_head)
-    assert [_wide_wins(m, *qkv) for m in (96, 128, 160, 192, 224, 256)] == [True, True, False, True, True, True]
-    assert [_wide_wins(m, *o) for m in (96, 128, 160, 192, 224, 256)] == [True, True, False, True, False, False]
+    assert [_wide_wins(m, *qkv) for m in (96, 128, 160, 192, 200, 224, 256)] == [True, True, True, True, False, True, True]
+    assert [_wide_wins(m, *o) for m in (96, 128, 160, 192, 200, 224, 256)] == [True, True, True, True, False, False, False]
     assert [_wide_silu_wins(m) for m in (96, 128, 129, 256)] == [True, True, False, False]
 
 

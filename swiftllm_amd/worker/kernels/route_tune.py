@@ -5,8 +5,8 @@ Both compute the same product (one rounding of an fp32-accumulated sum) but sum 
 is part of a deployment's numerics: it must not depend on a timing race inside a request, and every replica of a
 data-parallel deployment must answer alike.
 
-  * the measured table (r04 sweep: Llama-3-8B widths, bfloat16, ROCm 7.2) answers for the (N, K, dtype) classes it was
-    measured on (`MEASURED`);
+  * the measured table (r04 sweep, qkv / o re-measured with cold weights in r06d: Llama-3-8B widths, bfloat16, ROCm 7.2)
+    answers for the (N, K, dtype) classes it was measured on (`MEASURED`);
   * any other class is measured ONCE PER DEPLOYMENT, at `LlamaModel.load_weights()` time — before any request and before
     any hipGraph capture — for every 32-token bucket of 65..256 tokens (`prepare`, driven by kernels/linear.py:
     tune_wide_routes): a few launches of each side, the hand-written kernel taken when it wins by more than 3 %. The table
@@ -15,7 +15,7 @@ data-parallel deployment must answer alike.
     measures and every other replica READS the same answer;
   * `decide()` is a pure lookup: a class nobody measured goes to the library (deterministic), it never times anything,
     takes no lock and asks the driver for nothing;
-  * `SWIFTLLM_ROUTE_TUNE=table` pins the r04 table for every shape (tests that assert WHICH kernel ran), `=off` sends
+  * `SWIFTLLM_ROUTE_TUNE=table` pins the measured table for every shape (tests that assert WHICH kernel ran), `=off` sends
     every unmeasured shape to the library without measuring."""
 import json
 import os
@@ -43,17 +43,18 @@ def table_wide_wins(m: int, n: int, k: int) -> bool:
     the r04 sweep's six copies left 200-300 MB of them in the Infinity Cache, which flattered the library's 160-token
     kernels (o: 24 us then, 31.5 cold) — and with the token-split tiling of csrc/gemm_wide.hip; M = 136, 144, 160, 176, 192,
     208, 224, 256:
-        qkv  (N = 6144)  27/41  27/41  28/31  29/30  29/37  37/30  37/40  38/43   -> except (192, 208]
+        qkv  (N = 6144)  27/41  27/41  28/31  29/30  29/37  37/30  37/40  38/43   -> always
         o    (N = 4096)  22/28  22/24  22/32  23/26  24/36  29/27  29/29  30/27   -> up to 192
-    (up to 128 tokens both were already ours.) The plain up/gate projection only ties (53 / 54 at 128) and loses beyond;
-    its SiLU-gate form is `table_wide_silu_wins`."""
+    (up to 128 tokens both were already ours.) Thresholds sit on the 32-token bucket edges of the hipGraph replay cache
+    (`LlamaModel._decode_batch_bucket`) and nowhere else: a batch of 200 runs as 200 rows eagerly and as 224 rows in a replayed
+    graph, and both must take the same side — the library's one good qkv kernel at 208 tokens is therefore not used (the
+    bucket's replay shape, 224, is ours: `test_large_decode_batches_replay_their_hip_graph_bit_for_bit`). The plain up/gate
+    projection only ties (53 / 54 at 128) and loses beyond; its SiLU-gate form is `table_wide_silu_wins`."""
     if k >= 2 * n:
         return True
     if n > 8192:
         return False
-    if m <= 192:
-        return True
-    return n > 4096 and m > 208
+    return m <= 192 or n > 4096
 
 
 def table_wide_silu_wins(m: int) -> bool:

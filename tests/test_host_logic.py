@@ -723,9 +723,15 @@ def test_wide_gemm_routing_is_the_measured_table():
     for m in (65, 96, 128, 160, 192, 224, 256):
         assert _wide_wins(m, *down)
         assert not _wide_wins(m, *up_gate) and not _wide_wins(m, *lm_head)
-    assert [_wide_wins(m, *qkv) for m in (96, 128, 160, 192, 200, 224, 256)] == [True, True, True, True, False, True, True]
+    assert [_wide_wins(m, *qkv) for m in (96, 128, 160, 192, 200, 224, 256)] == [True, True, True, True, True, True, True]
     assert [_wide_wins(m, *o) for m in (96, 128, 160, 192, 200, 224, 256)] == [True, True, True, True, False, False, False]
     assert [_wide_silu_wins(m) for m in (96, 128, 129, 256)] == [True, True, False, False]
+    # a threshold inside a replay bucket would route a batch differently in eager launches and in its padded graph
+    from swiftllm_amd.worker.model import LlamaModel
+    for shape in (qkv, o, up_gate, down, lm_head, (8192, 2048), (3072, 2048)):
+        for m in range(65, 257):
+            assert _wide_wins(m, *shape) == _wide_wins(LlamaModel._decode_batch_bucket(None, m), *shape), (m, shape)
+            assert _wide_silu_wins(m) == _wide_silu_wins(LlamaModel._decode_batch_bucket(None, m)), m
 
 
 def test_bench_prefill_flops_and_full_depth_cpu_baseline():

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Where does gemm_wide.hip's time go at 128 / 256 tokens? Timing-only ablations (WRONG results) as variant libraries built
-# beforehand with `python -m swiftllm_amd.csrc.build --tag gw<name> --swap gemm_wide.hip=/tmp/gw_<name>.hip`:
+# beforehand by `python tools/make_gemm_wide_ablations.py` (csrc/libswiftllm_hip_gw<name>.so):
 #   plain   W loads without the non-temporal hint (a real candidate, right results)
 #   nox     no global loads of x (staging registers filled from a register)        -> what the x path through L2/L1 costs
 #   nolds   B fragments taken from registers instead of LDS                        -> what the LDS reads cost

@@ -26,6 +26,10 @@
 //   * SiLU-gate mode: the first half of the waves own `up` tiles, the second half the `gate` tiles of the same
 //     columns; activated gate tiles change hands through the (then idle) x buffers, MT/2 token blocks per round;
 //     same rounding points as linear -> silu_and_mul_inplace (silu_and_mul.py:16-23).
+//   * r06d, two variants of the same loop, each shipped where it measured faster (gemm_wide_plan):
+//     TS = 2 — a wave owns 64 rows of W x half of the token blocks, every B fragment feeds two MFMAs (short K-chunks: qkv /
+//     o up to 192 tokens); BQ = 2 — the B fragments of k-step kk+1 requested before the MFMAs of kk (SiLU-gate mode up to
+//     192 tokens). Timing-only ablations of the loop: tools/make_gemm_wide_ablations.py.
 // Bits: every output is the fp32 sum over k in ascending 16-element steps inside a K-chunk, chunks added in slab
 // order — the summation order of the M <= 64 kernels at the same split count.
 #include "swl_common.h"

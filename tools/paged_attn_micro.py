@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--dtype", default="bfloat16")
     ap.add_argument("--iters", type=int, default=256)
     ap.add_argument("--sbs", type=int, default=0, help="override the split-K width")
+    ap.add_argument("--slab-copies", type=int, default=1, help="with --qkv: distinct slab tensors cycled through (cold slabs)")
     ap.add_argument("--qkv", type=int, default=0, help="k-splits of fused-qkv slabs: time swl_paged_attn_decode_qkv "
                                                        "(rotary + KV store in the prologue), the variant a decode step runs")
     a = ap.parse_args()
@@ -71,18 +72,21 @@ def main():
         st.position_indices = (st.decoding_seq_lens - 1).contiguous()
         ang = torch.rand(n + 8, D // 2, device=dev) * 6.28
         st.position_cos, st.position_sin = torch.cos(ang).to(dtype), torch.sin(ang).to(dtype)
-        slabs = torch.randn(a.qkv, B, (H + 2 * KVH) * D, device=dev, dtype=torch.float32) * 0.5
-        slab_part = SplitKPartials(slabs, a.qkv, B, (H + 2 * KVH) * D, dtype)
-        run = lambda layer: paged_attention_from_qkv_splitk(slab_part, kc, vc, bt, mc, ec, st, layer, o)   # noqa: E731
+        # --slab-copies N: cycle through N distinct slab tensors (in the decode step the slabs were written by the previous
+        # kernel on other XCDs and are read cold; one tensor re-read every launch sits in the reader's L2)
+        slab_parts = [SplitKPartials(torch.randn(a.qkv, B, (H + 2 * KVH) * D, device=dev, dtype=torch.float32) * 0.5,
+                                     a.qkv, B, (H + 2 * KVH) * D, dtype) for _ in range(max(1, a.slab_copies))]
+        run = lambda layer: paged_attention_from_qkv_splitk(slab_parts[layer % len(slab_parts)], kc, vc, bt, mc, ec, st,  # noqa: E731
+                                                            layer % L, o)
     else:
         run = lambda layer: K.paged_attention(q, kc, vc, bt, mc, ec, st, layer, o)   # noqa: E731
     for i in range(min(a.iters, 2 * L)):
-        run(i % L)
+        run(i if a.qkv else i % L)
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     start.record()
     for i in range(a.iters):
-        run(i % L)
+        run(i if a.qkv else i % L)
     stop.record()
     stop.synchronize()
     us = start.elapsed_time(stop) * 1e3 / a.iters
@@ -93,7 +97,7 @@ def main():
     q_bytes = a.qkv * B * (H + 2 * KVH) * D * 4 if a.qkv else B * H * D * e
     alg = kv + q_bytes + B * H * D * e + part
     kernel = ("paged_attn_phase1_kernel<%s, D=%d, G=%d%s>" % (a.dtype, D, H // KVH, ", QKV: rotary + KV store in the prologue" if a.qkv else ""))
-    print(json.dumps(dict(kernel=kernel, algorithmic_bytes=alg, shape=a.shape, qkv_slabs=a.qkv, lib=os.environ.get("SWIFTLLM_HIP_LIB", "default"), dtype=a.dtype, H=H, KVH=KVH, D=D, batch=B, len=n, seq_block_size=sbs,
+    print(json.dumps(dict(kernel=kernel, algorithmic_bytes=alg, shape=a.shape, qkv_slabs=a.qkv, slab_copies=a.slab_copies, lib=os.environ.get("SWIFTLLM_HIP_LIB", "default"), dtype=a.dtype, H=H, KVH=KVH, D=D, batch=B, len=n, seq_block_size=sbs,
                           num_seq_blocks=nsb, workgroups=B * KVH * nsb, us_per_op=round(us, 2),
                           alg_bytes=alg, kv_bytes=kv, GBps=round(alg / us / 1e3, 1),
                           frac_of_8TBps=round(alg / us / 1e3 / 8000, 4), iters=a.iters)))

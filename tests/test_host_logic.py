@@ -785,3 +785,17 @@ def test_decode_engine_stream_packing_matches_the_kernel_addressing():
     assert lib.swl_decode_engine_slots_per_layer(4096, 32, 8, 14336) == 104        # 436 MB per layer / 256 CUs / 16 KiB
     assert lib.swl_decode_engine_supported(4096, 32, 32, 128, 11008, 256) == 0     # Llama-2-7B: FFN rows do not divide
     assert lib.swl_decode_engine_supported(4096, 32, 8, 128, 14336, 304) == 0
+
+
+def test_gemm_wide_ablation_tool_still_matches_the_kernel_source():
+    """tools/make_gemm_wide_ablations.py edits csrc/gemm_wide.hip by exact text: every pattern must occur exactly once in the
+    shipped source, or the timing-only variants of DESIGN.md section 4.7 can no longer be rebuilt."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_gemm_wide_ablations", os.path.join(root, "tools", "make_gemm_wide_ablations.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    src = open(tool.SRC).read()
+    for name, edits in tool.EDITS.items():
+        for old, _new in edits:
+            assert src.count(old) == 1, (name, old[:60])
